@@ -1,0 +1,391 @@
+// CPU ORACLE — TEST INFRASTRUCTURE ONLY (see oracle.hpp).
+// Restates PathTracer/Box.cs, Ray.cs, Triangle.cs and Accelerator.cs.
+#include "oracle.hpp"
+#include <cmath>
+#include <limits>
+#include <algorithm>
+
+namespace oracle {
+
+static const float Epsilon = 0.00001f;   // Accelerator.cs:10
+static const int LeafNodeSize = 3;       // Accelerator.cs:11
+static const int BucketCount = 8;        // Accelerator.cs:12
+static const float INF = std::numeric_limits<float>::infinity();
+
+// Box.cs:14-18
+Box BoxNegative() { return Box{{INF, INF, INF}, {-INF, -INF, -INF}}; }
+
+// Box.cs:20-23
+Vec3 BoxCentroid(const Box& b) { return 0.5f * b.Min + 0.5f * b.Max; }
+
+// Box.cs:25-43, Vector.cs:28-31
+int BoxDomain(const Box& b) {
+    Vec3 dim = b.Max - b.Min;
+    float l = MathFMax(MathFMax(dim.x, dim.y), dim.z);
+    if (l == dim.x) return 0;
+    else if (l == dim.y) return 1;
+    else return 2;
+}
+
+// Box.cs:45-49
+float BoxArea(const Box& b) {
+    Vec3 d = b.Max - b.Min;
+    return 2.0f * (d.x * d.y + d.x * d.z + d.y * d.z);
+}
+
+// Box.cs:81-88
+Box BoxUnion(const Box& a, const Box& b) {
+    Box r;
+    r.Max = Vec3Max(a.Max, b.Max);
+    r.Min = Vec3Min(a.Min, b.Min);
+    return r;
+}
+
+// Box.cs:90-102
+Box BoxFromTriangle(const Triangle& t) {
+    Vec3 e{0.00001f, 0.00001f, 0.00001f};
+    Box r;
+    r.Max = Vec3Max(Vec3Max(t.V1.Position, t.V2.Position), t.V3.Position) + e;
+    r.Min = Vec3Min(Vec3Min(t.V1.Position, t.V2.Position), t.V3.Position) - e;
+    return r;
+}
+
+// Ray.cs:14-19
+Ray MakeRay(Vec3 origin, Vec3 direction) {
+    Ray r;
+    r.Origin = origin;
+    r.Direction = direction;
+    r.Inverse = {1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z};
+    return r;
+}
+
+// Box.cs:51-79
+bool BoxIntersect(const Box& b, const Ray& ray, float* tmin_out, float* tmax_out) {
+    float t1 = (b.Min.x - ray.Origin.x) * ray.Inverse.x;
+    float t2 = (b.Max.x - ray.Origin.x) * ray.Inverse.x;
+    float t3 = (b.Min.y - ray.Origin.y) * ray.Inverse.y;
+    float t4 = (b.Max.y - ray.Origin.y) * ray.Inverse.y;
+    float t5 = (b.Min.z - ray.Origin.z) * ray.Inverse.z;
+    float t6 = (b.Max.z - ray.Origin.z) * ray.Inverse.z;
+    float tmin = MathFMax(MathFMax(MathFMin(t1, t2), MathFMin(t3, t4)), MathFMin(t5, t6));
+    float tmax = MathFMin(MathFMin(MathFMax(t1, t2), MathFMax(t3, t4)), MathFMax(t5, t6));
+    if (tmin_out) *tmin_out = tmin;
+    if (tmax_out) *tmax_out = tmax;
+    return (tmax > 0.0f && tmin < tmax);
+}
+
+// Triangle.cs:15-47.  Returns true when the hit was accepted (closer than i.Distance).
+bool TriangleIntersect(const Triangle& t, const Ray& ray, Intersection& i, int triIndex) {
+    Vec3 edge1 = t.V2.Position - t.V1.Position;
+    Vec3 edge2 = t.V3.Position - t.V1.Position;
+
+    Vec3 h = Cross(ray.Direction, edge2);
+    float a = Dot(edge1, h);
+
+    float f = 1.0f / a;
+    Vec3 s = ray.Origin - t.V1.Position;
+    float u = f * Dot(s, h);
+
+    if (u < 0.0 || u > 1.0) return false;
+
+    Vec3 q = Cross(s, edge1);
+    float v = f * Dot(ray.Direction, q);
+
+    if (v < 0.0f || u + v > 1.0f) return false;
+
+    float dist = f * Dot(edge2, q);
+
+    if (dist > 0 && dist < i.Distance) {
+        i.Distance = dist;
+        i.Point = ray.Origin + ray.Direction * dist;   // Ray.cs:21-24
+        i.Tri = triIndex;
+        i.U = u;
+        i.V = v;
+        return true;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------- Accelerator
+// Accelerator.cs:38-49
+void Accelerator::AddTriangle(const Triangle& triangle) {
+    references.push_back(triangle);
+    Box box = BoxFromTriangle(triangle);
+    primitives.push_back(Primitive{(int)references.size() - 1, box, BoxCentroid(box)});
+}
+
+// Accelerator.cs:179-186
+void Accelerator::Clear() {
+    references.clear();
+    primitives.clear();
+    triangles.clear();
+    nodes.clear();
+}
+
+// Accelerator.cs:51-111 (literal: far child is popped first, no cull on a single hit)
+void Accelerator::Intersect(const Ray& ray, Intersection& i) const {
+    if (nodes.empty()) return;
+    if (!BoxIntersect(nodes[0].Bounds, ray, nullptr, nullptr)) return;
+
+    std::vector<int> stack;
+    stack.push_back(0);
+
+    while (!stack.empty()) {
+        const Node& node = nodes[stack.back()];
+        stack.pop_back();
+
+        if (node.Count > 0) {
+            int to = node.LeftFirst + node.Count;
+            for (int j = node.LeftFirst; j < to; j++) TriangleIntersect(triangles[j], ray, i, j);
+        } else {
+            float lt, rt;
+            bool lhit = BoxIntersect(nodes[node.LeftFirst].Bounds, ray, &lt, nullptr);
+            bool rhit = BoxIntersect(nodes[node.LeftFirst + 1].Bounds, ray, &rt, nullptr);
+
+            if (lhit && rhit) {
+                if (lt < rt && lt < i.Distance) {
+                    stack.push_back(node.LeftFirst);
+                    stack.push_back(node.LeftFirst + 1);
+                } else if (rt < i.Distance) {
+                    stack.push_back(node.LeftFirst + 1);
+                    stack.push_back(node.LeftFirst);
+                }
+            } else {
+                if (lhit) stack.push_back(node.LeftFirst);
+                else if (rhit) stack.push_back(node.LeftFirst + 1);
+            }
+        }
+    }
+}
+
+// Canonical closest hit: the minimum over all accepted Möller–Trumbore hits,
+// ties broken by the smallest triangle index.  Near-first order, subtrees
+// whose entry distance exceeds the best hit are skipped (tmin > best: a
+// subtree entered exactly AT the best distance is still visited so that an
+// equal-distance triangle with a smaller index can win the tie).
+static inline bool AcceptCanonical(const Triangle& t, const Ray& ray, Intersection& best, int j) {
+    Intersection probe;
+    probe.Distance = INF;
+    probe.Tri = -1;
+    if (!TriangleIntersect(t, ray, probe, j)) return false;
+    if (probe.Distance < best.Distance || (probe.Distance == best.Distance && j < best.Tri)) {
+        best = probe;
+        return true;
+    }
+    return false;
+}
+
+void Accelerator::IntersectCanonical(const Ray& ray, Intersection& i, TraversalStats* st) const {
+    if (st) st->rays++;
+    if (nodes.empty()) return;
+    if (!BoxIntersect(nodes[0].Bounds, ray, nullptr, nullptr)) return;
+
+    struct Entry { int node; float tmin; };
+    std::vector<Entry> stack;
+    stack.push_back({0, -INF});
+    while (!stack.empty()) {
+        Entry e = stack.back();
+        stack.pop_back();
+        if (e.tmin > i.Distance) continue;
+        const Node& node = nodes[e.node];
+        if (node.Count > 0) {
+            int to = node.LeftFirst + node.Count;
+            for (int j = node.LeftFirst; j < to; j++) {
+                if (st) st->tris++;
+                AcceptCanonical(triangles[j], ray, i, j);
+            }
+        } else {
+            if (st) st->steps++;
+            float lt, rt;
+            bool lhit = BoxIntersect(nodes[node.LeftFirst].Bounds, ray, &lt, nullptr);
+            bool rhit = BoxIntersect(nodes[node.LeftFirst + 1].Bounds, ray, &rt, nullptr);
+            lhit = lhit && !(lt > i.Distance);
+            rhit = rhit && !(rt > i.Distance);
+            if (lhit && rhit) {
+                if (rt < lt) {   // right is nearer: push left (far) first
+                    stack.push_back({node.LeftFirst, lt});
+                    stack.push_back({node.LeftFirst + 1, rt});
+                } else {
+                    stack.push_back({node.LeftFirst + 1, rt});
+                    stack.push_back({node.LeftFirst, lt});
+                }
+            } else if (lhit) stack.push_back({node.LeftFirst, lt});
+            else if (rhit) stack.push_back({node.LeftFirst + 1, rt});
+        }
+    }
+}
+
+void Accelerator::IntersectBrute(const Ray& ray, Intersection& i) const {
+    for (int j = 0; j < (int)triangles.size(); j++) AcceptCanonical(triangles[j], ray, i, j);
+}
+
+bool Accelerator::Occluded(const Ray& ray, float tmax, TraversalStats* st) const {
+    if (st) st->rays++;
+    if (nodes.empty()) return false;
+    if (!BoxIntersect(nodes[0].Bounds, ray, nullptr, nullptr)) return false;
+    std::vector<int> stack;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        const Node& node = nodes[stack.back()];
+        stack.pop_back();
+        if (node.Count > 0) {
+            int to = node.LeftFirst + node.Count;
+            for (int j = node.LeftFirst; j < to; j++) {
+                if (st) st->tris++;
+                Intersection probe;
+                probe.Distance = tmax;
+                probe.Tri = -1;
+                if (TriangleIntersect(triangles[j], ray, probe, j)) return true;
+            }
+        } else {
+            if (st) st->steps++;
+            float lt, rt;
+            bool lhit = BoxIntersect(nodes[node.LeftFirst].Bounds, ray, &lt, nullptr);
+            bool rhit = BoxIntersect(nodes[node.LeftFirst + 1].Bounds, ray, &rt, nullptr);
+            lhit = lhit && lt < tmax;
+            rhit = rhit && rt < tmax;
+            if (lhit && rhit) {
+                if (rt < lt) { stack.push_back(node.LeftFirst); stack.push_back(node.LeftFirst + 1); }
+                else { stack.push_back(node.LeftFirst + 1); stack.push_back(node.LeftFirst); }
+            } else if (lhit) stack.push_back(node.LeftFirst);
+            else if (rhit) stack.push_back(node.LeftFirst + 1);
+        }
+    }
+    return false;
+}
+
+int Accelerator::MaxDepth() const {
+    if (nodes.empty()) return 0;
+    int best = 0;
+    std::vector<std::pair<int, int>> stack;
+    stack.push_back({0, 1});
+    while (!stack.empty()) {
+        auto [n, d] = stack.back();
+        stack.pop_back();
+        best = std::max(best, d);
+        if (nodes[n].Count <= 0) {
+            stack.push_back({nodes[n].LeftFirst, d + 1});
+            stack.push_back({nodes[n].LeftFirst + 1, d + 1});
+        }
+    }
+    return best;
+}
+
+// Accelerator.cs:113-134
+void Accelerator::Build() {
+    nodes.clear();
+    triangles.clear();
+
+    nodes.push_back(Node{Bounds(0, (int)primitives.size()), 0, (int)primitives.size()});
+
+    Subdivide(0);
+
+    triangles.reserve(primitives.size());
+    for (size_t i = 0; i < primitives.size(); i++) {
+        int j = primitives[i].Index;
+        triangles.push_back(references[j]);
+    }
+}
+
+// Accelerator.cs:136-177
+void Accelerator::Subdivide(int index) {
+    if (nodes[index].Count < LeafNodeSize) return;
+
+    int p = Partition(nodes[index]);
+    if (p < 0) return;
+
+    Node parent = nodes[index];
+    nodes.push_back(Node{Bounds(parent.LeftFirst, p), parent.LeftFirst, p});
+    nodes.push_back(Node{Bounds(parent.LeftFirst + p, parent.Count - p), parent.LeftFirst + p, parent.Count - p});
+
+    nodes[index].LeftFirst = (int)nodes.size() - 2;
+    // the split axis is stored through a negative count: -1 x, -2 y, -3 z
+    nodes[index].Count = BoxDomain(parent.Bounds) * -1 - 1;
+
+    int left = nodes[index].LeftFirst;
+    Subdivide(left);
+    Subdivide(left + 1);
+}
+
+// Accelerator.cs:188-280
+int Accelerator::Partition(const Node& node) {
+    int domain = BoxDomain(node.Bounds);
+    auto axis = [domain](const Vec3& v) { return domain == 0 ? v.x : (domain == 1 ? v.y : v.z); };
+
+    Box bounds = CentroidBounds(node.LeftFirst, node.Count);
+
+    float k0 = axis(bounds.Min);
+    float l = axis(bounds.Max) - k0;
+
+    if (l < Epsilon) return -1;
+
+    float k1 = ((float)BucketCount - Epsilon) / l;
+
+    std::vector<Primitive> bins[BucketCount];
+    Box domains[BucketCount];
+    for (int i = 0; i < BucketCount; i++) domains[i] = BoxNegative();
+
+    // bin primitives
+    for (int i = node.LeftFirst; i < node.LeftFirst + node.Count; i++) {
+        float c = axis(primitives[i].Centroid);
+        float b = (c - k0) * k1;
+        int j = (int)b;
+        bins[j].push_back(primitives[i]);
+        domains[j] = BoxUnion(domains[j], primitives[i].Bounds);
+    }
+
+    int partition = -1;
+    float cost = BoxArea(node.Bounds) * (float)node.Count;
+
+    int ln = 0, rn = node.Count;
+
+    // select best bin split
+    for (int i = 1; i < BucketCount; i++) {
+        ln += (int)bins[i - 1].size();
+        rn -= (int)bins[i - 1].size();
+
+        Box lb = BoxNegative();
+        Box rb = BoxNegative();
+
+        for (int j = 0; j < i; j++) lb = BoxUnion(domains[j], lb);
+        for (int j = i; j < BucketCount; j++) rb = BoxUnion(domains[j], rb);
+
+        float c = (float)ln * BoxArea(lb) + (float)rn * BoxArea(rb);
+
+        if (c < cost) {
+            partition = ln;
+            cost = c;
+        }
+    }
+
+    if (partition < 0) return -1;
+
+    int p = node.LeftFirst;
+    for (int i = 0; i < BucketCount; i++)
+        for (size_t j = 0; j < bins[i].size(); j++) primitives[p++] = bins[i][j];
+
+    return partition;
+}
+
+// Accelerator.cs:282-292
+Box Accelerator::Bounds(int first, int count) const {
+    Box bounds = BoxNegative();
+    for (int i = first; i < first + count; i++) bounds = BoxUnion(primitives[i].Bounds, bounds);
+    return bounds;
+}
+
+// Accelerator.cs:294-310
+Box Accelerator::CentroidBounds(int first, int count) const {
+    Vec3 min{INF, INF, INF};
+    Vec3 max{-INF, -INF, -INF};
+    for (int i = first; i < first + count; i++) {
+        min = Vec3Min(primitives[i].Centroid, min);
+        max = Vec3Max(primitives[i].Centroid, max);
+    }
+    Box b;
+    b.Max = max;
+    b.Min = min;
+    return b;
+}
+
+}  // namespace oracle
