@@ -1,0 +1,142 @@
+/*
+ * pt_hip.h — C ABI of libpt_hip.so, the MI355X (gfx950) wavefront path-tracing core.
+ *
+ * Drop-in boundary: the reference's C# host keeps Scene / Camera / Material /
+ * Triangle / Accelerator as they are and replaces its OpenGL compute dispatch
+ * by P/Invoke into these entry points.  Every array crosses the boundary in
+ * the host's own blittable layout:
+ *
+ *   Material  48 B  PathTracer/Material.cs:7-28      (Color@0 Emissive@16 Type@32 Index@36 Roughness@40)
+ *   Triangle 112 B  PathTracer/Triangle.cs:7-13      (V1@0 V2@32 V3@64 Material@96; Vertex = Position@0 Normal@16)
+ *   Node      32 B  PathTracer/Node.cs:5-10          (Bounds.Min@0 Bounds.Max@12 LeftFirst@24 Count@28)
+ *   RenderState 32 B, FrameState 112 B               PathTracer/State.cs:20-41
+ *
+ * All functions return PT_OK (0) or a negative pt_status; nothing throws across
+ * the boundary.  pt_last_error() returns a message owned by the context (or by
+ * the library when ctx is NULL).  A context is used by one thread at a time.
+ * The host owns every input array and every output buffer; the library owns
+ * all device memory.
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_ctx pt_ctx;
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_E_INVALID_ARG = -1,
+    PT_E_NO_DEVICE = -2,
+    PT_E_OOM = -3,
+    PT_E_HIP = -4,
+    PT_E_BAD_BVH = -5,
+    PT_E_STATE = -6
+} pt_status;
+
+/* Constants the reference hard-codes, as fields (reference values are the defaults
+ * written by pt_default_config). */
+typedef struct pt_config {
+    int32_t struct_size;        /* sizeof(pt_config), for versioning */
+    int32_t device;             /* HIP device ordinal */
+    int32_t nee;                /* 1 = next-event estimation at diffuse vertices (not in the reference) */
+    int32_t rng_mode;           /* 0 = reference seeding (generate.glsl:174, shade.glsl:352), 1 = decorrelated hash */
+    int32_t tile_rank;          /* this context renders pixel groups g with g % tile_world == tile_rank */
+    int32_t tile_world;
+    int32_t samples_per_batch;  /* samples traced concurrently; 0 = choose from the pixel count */
+    int32_t traversal_stats;    /* 1 = count BVH steps / triangle tests (slower instrumented kernels) */
+    int32_t stage_timing;       /* 1 = bracket every stage launch with events (pt_get_stats ms_*) */
+    int32_t reserved[7];
+} pt_config;
+
+typedef struct pt_stats {
+    uint64_t paths;             /* primary rays generated */
+    uint64_t extend_rays;       /* rays traced by extend (primary + bounce) */
+    uint64_t shadow_rays;       /* rays traced by connect */
+    uint64_t extend_steps;      /* node-pair fetches in extend   (traversal_stats) */
+    uint64_t extend_tris;       /* triangle tests in extend      (traversal_stats) */
+    uint64_t shadow_steps;
+    uint64_t shadow_tris;
+    uint64_t stack_overflows;   /* rays dropped because the traversal stack was exhausted (must stay 0) */
+    uint32_t extend_launches, shade_launches, connect_launches, generate_launches;
+    float ms_generate, ms_extend, ms_shade, ms_connect;   /* summed event time per stage (stage_timing) */
+    float ms_render;            /* wall time of the last pt_render + pt_synchronize pair measured by events */
+    float reserved[3];
+} pt_stats;
+
+/* ---- lifetime --------------------------------------------------------------
+ * Replaces: new Wavefront() + the three ShaderProgram compiles, PathTracer/Wavefront.cs:22-38. */
+int pt_default_config(pt_config* cfg);
+int pt_create(const pt_config* cfg, pt_ctx** out);
+int pt_destroy(pt_ctx* ctx);
+const char* pt_last_error(pt_ctx* ctx);
+
+/* Replaces: Scene.CopyToDevice -> Buffer<T>.CopyToDevice for bindings 10/11/12,
+ * PathTracer/Scene.cs:176-183, PathTracer/Library/Graphics/Buffer.cs:94-126.
+ * Copies; validates child indices and leaf ranges (PT_E_BAD_BVH); repacks on the
+ * device into 64-byte sibling-pair nodes and 48-byte hot/cold triangle records;
+ * builds the emissive-triangle table. */
+int pt_upload_scene(pt_ctx* ctx, const void* materials, int32_t n_materials,
+                    const void* triangles, int32_t n_triangles,
+                    const void* nodes, int32_t n_nodes);
+
+/* Replaces: Game.Resize -> new Image(w,h) + Wavefront.Allocate(w*h), PathTracer/Game.cs:138-151,
+ * PathTracer/Wavefront.cs:67-81.  (Re)allocates ray queues and the accumulator, zeroes it. */
+int pt_resize(pt_ctx* ctx, int32_t width, int32_t height);
+
+/* Replaces: renderState.CopyToDevice (UBO 0), PathTracer/Game.cs:147-150.  Width/Height must equal pt_resize's. */
+int pt_set_render_state(pt_ctx* ctx, const void* render_state32);
+
+/* Replaces: frameState.Data.Samples = 0 (camera moved / key R), PathTracer/Game.cs:157-165. */
+int pt_reset_accumulation(pt_ctx* ctx);
+
+/* Replaces: frameState.CopyToDevice + Wavefront.Invoke, PathTracer/Game.cs:187-191, PathTracer/Wavefront.cs:40-56.
+ * Traces `spp` samples; sample s uses frames = FrameState.Frames + s.  spp = 1, max_bounces = 10 is one
+ * Wavefront.Invoke().  Work is enqueued on the context's stream; the call does not wait for it. */
+int pt_render(pt_ctx* ctx, const void* frame_state112, int32_t spp, int32_t max_bounces);
+int pt_synchronize(pt_ctx* ctx);
+
+/* Replaces: the rgba32f image bound at unit 0 that the quad shader displays, PathTracer/Library/Graphics/Image.cs:7-19,
+ * PathTracer/Shaders/Quad/fragment.glsl:7-11.  Blocking; rgba = width*height*4 floats, pixel = x + y*width, row 0 = bottom.
+ * Value = sum of sample contributions / samples accumulated since the last reset. */
+int pt_read_image(pt_ctx* ctx, float* rgba);
+
+/* GPU twin of Scene.Intersect, PathTracer/Scene.cs:35-45 / PathTracer/Accelerator.cs:51-111 (used by
+ * Camera.GetFocalDistance, PathTracer/Camera.cs:89-95).  o_d = n x 6 floats (origin, direction).
+ * tri = index into the uploaded triangle array, -1 = miss; t = distance (+inf on a miss); uv may be NULL. */
+int pt_trace_closest(pt_ctx* ctx, const float* o_d, int32_t n, int32_t* tri, float* t, float* uv);
+
+/* Any hit with 0 < t < tmax[i] (the connect stage's query).  No reference counterpart: the reference has no shadow rays. */
+int pt_trace_occluded(pt_ctx* ctx, const float* o_d, const float* tmax, int32_t n, uint8_t* occluded);
+
+/* Runs the generate stage alone (generate.glsl:170-200) for local thread indices [0,n) of one sample and copies the
+ * rays back: o_d n x 6, pixel n (0xFFFFFFFF where the thread emits no ray).  Parity/debug entry. */
+int pt_generate_rays(pt_ctx* ctx, const void* frame_state112, int32_t n, float* o_d, uint32_t* pixel);
+
+int pt_get_stats(pt_ctx* ctx, pt_stats* out);
+int pt_reset_stats(pt_ctx* ctx);
+
+/* Runtime switches: key is one of PT_OPT_*; takes effect at the next pt_render. */
+enum { PT_OPT_NEE = 1, PT_OPT_RNG_MODE = 2, PT_OPT_TRAVERSAL_STATS = 3, PT_OPT_STAGE_TIMING = 4, PT_OPT_SAMPLES_PER_BATCH = 5 };
+int pt_set_option(pt_ctx* ctx, int32_t key, int32_t value);
+
+/* ---- multi-GPU tiles ---------------------------------------------------------
+ * Each rank accumulates only its own pixel groups.  pt_accum_device exposes the rank-local accumulator
+ * (float4 per local slot, slots = local groups * 64, padded to the same length on every rank) so the caller can
+ * gather it with RCCL; pt_assemble_tiles de-interleaves `world` gathered accumulators into a row-major image.
+ * No reference counterpart (the reference is single-GPU). */
+int pt_accum_device(pt_ctx* ctx, void** device_ptr, uint64_t* n_slots_padded, uint32_t* samples);
+int pt_assemble_tiles(pt_ctx* ctx, const void* gathered_device, int32_t world, uint32_t samples, float* rgba_host);
+
+/* Stream the context enqueues on (hipStream_t as void*), for callers that order their own work after it. */
+int pt_stream(pt_ctx* ctx, void** stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_HIP_H */

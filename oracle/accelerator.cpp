@@ -158,11 +158,15 @@ void Accelerator::Intersect(const Ray& ray, Intersection& i) const {
     }
 }
 
-// Canonical closest hit: the minimum over all accepted Möller–Trumbore hits,
-// ties broken by the smallest triangle index.  Near-first order, subtrees
-// whose entry distance exceeds the best hit are skipped (tmin > best: a
-// subtree entered exactly AT the best distance is still visited so that an
-// equal-distance triangle with a smaller index can win the tie).
+// Canonical closest hit: the minimum over all accepted Möller–Trumbore hits, ties broken by
+// the smallest triangle index.  The visiting order is the one the GPU kernels use, step for
+// step, so that distance culling (which compares box entry distances with triangle
+// distances, two differently rounded quantities) takes the same decisions on both sides:
+//   one step = one sibling pair; both children slab-tested; a child whose entry distance is
+//   beyond the best hit is skipped (tmin > best; a child entered exactly AT the best distance
+//   is still visited so an equal-distance triangle with a smaller index can win); hit leaf
+//   children are tested at once, left then right; of two hit interior children the nearer
+//   is visited next and the other pushed.
 static inline bool AcceptCanonical(const Triangle& t, const Ray& ray, Intersection& best, int j) {
     Intersection probe;
     probe.Distance = INF;
@@ -179,38 +183,35 @@ void Accelerator::IntersectCanonical(const Ray& ray, Intersection& i, TraversalS
     if (st) st->rays++;
     if (nodes.empty()) return;
     if (!BoxIntersect(nodes[0].Bounds, ray, nullptr, nullptr)) return;
-
-    struct Entry { int node; float tmin; };
-    std::vector<Entry> stack;
-    stack.push_back({0, -INF});
-    while (!stack.empty()) {
-        Entry e = stack.back();
-        stack.pop_back();
-        if (e.tmin > i.Distance) continue;
-        const Node& node = nodes[e.node];
-        if (node.Count > 0) {
-            int to = node.LeftFirst + node.Count;
-            for (int j = node.LeftFirst; j < to; j++) {
-                if (st) st->tris++;
-                AcceptCanonical(triangles[j], ray, i, j);
-            }
-        } else {
-            if (st) st->steps++;
-            float lt, rt;
-            bool lhit = BoxIntersect(nodes[node.LeftFirst].Bounds, ray, &lt, nullptr);
-            bool rhit = BoxIntersect(nodes[node.LeftFirst + 1].Bounds, ray, &rt, nullptr);
-            lhit = lhit && !(lt > i.Distance);
-            rhit = rhit && !(rt > i.Distance);
-            if (lhit && rhit) {
-                if (rt < lt) {   // right is nearer: push left (far) first
-                    stack.push_back({node.LeftFirst, lt});
-                    stack.push_back({node.LeftFirst + 1, rt});
-                } else {
-                    stack.push_back({node.LeftFirst + 1, rt});
-                    stack.push_back({node.LeftFirst, lt});
-                }
-            } else if (lhit) stack.push_back({node.LeftFirst, lt});
-            else if (rhit) stack.push_back({node.LeftFirst + 1, rt});
+    auto testLeaf = [&](const Node& leaf) {
+        for (int j = leaf.LeftFirst; j < leaf.LeftFirst + leaf.Count; j++) {
+            if (st) st->tris++;
+            AcceptCanonical(triangles[j], ray, i, j);
+        }
+    };
+    if (nodes[0].Count > 0) { testLeaf(nodes[0]); return; }
+    std::vector<int> stack;
+    int cur = nodes[0].LeftFirst;
+    while (true) {
+        if (st) st->steps++;
+        const Node& L = nodes[cur];
+        const Node& R = nodes[cur + 1];
+        float lt, rt;
+        bool lhit = BoxIntersect(L.Bounds, ray, &lt, nullptr);
+        bool rhit = BoxIntersect(R.Bounds, ray, &rt, nullptr);
+        lhit = lhit && !(lt > i.Distance);
+        rhit = rhit && !(rt > i.Distance);
+        if (lhit && L.Count > 0) { testLeaf(L); lhit = false; }
+        if (rhit && R.Count > 0) { testLeaf(R); rhit = false; }
+        if (lhit && rhit) {
+            if (rt < lt) { stack.push_back(L.LeftFirst); cur = R.LeftFirst; }
+            else { stack.push_back(R.LeftFirst); cur = L.LeftFirst; }
+        } else if (lhit) cur = L.LeftFirst;
+        else if (rhit) cur = R.LeftFirst;
+        else {
+            if (stack.empty()) break;
+            cur = stack.back();
+            stack.pop_back();
         }
     }
 }
@@ -219,36 +220,45 @@ void Accelerator::IntersectBrute(const Ray& ray, Intersection& i) const {
     for (int j = 0; j < (int)triangles.size(); j++) AcceptCanonical(triangles[j], ray, i, j);
 }
 
+// Any accepted hit with 0 < t < tmax, visiting in the same order as IntersectCanonical;
+// children whose entry distance is not below tmax are skipped.
 bool Accelerator::Occluded(const Ray& ray, float tmax, TraversalStats* st) const {
     if (st) st->rays++;
     if (nodes.empty()) return false;
     if (!BoxIntersect(nodes[0].Bounds, ray, nullptr, nullptr)) return false;
+    auto testLeaf = [&](const Node& leaf) {
+        for (int j = leaf.LeftFirst; j < leaf.LeftFirst + leaf.Count; j++) {
+            if (st) st->tris++;
+            Intersection probe;
+            probe.Distance = INF;
+            probe.Tri = -1;
+            if (TriangleIntersect(triangles[j], ray, probe, j) && probe.Distance < tmax) return true;
+        }
+        return false;
+    };
+    if (nodes[0].Count > 0) return testLeaf(nodes[0]);
     std::vector<int> stack;
-    stack.push_back(0);
-    while (!stack.empty()) {
-        const Node& node = nodes[stack.back()];
-        stack.pop_back();
-        if (node.Count > 0) {
-            int to = node.LeftFirst + node.Count;
-            for (int j = node.LeftFirst; j < to; j++) {
-                if (st) st->tris++;
-                Intersection probe;
-                probe.Distance = tmax;
-                probe.Tri = -1;
-                if (TriangleIntersect(triangles[j], ray, probe, j)) return true;
-            }
-        } else {
-            if (st) st->steps++;
-            float lt, rt;
-            bool lhit = BoxIntersect(nodes[node.LeftFirst].Bounds, ray, &lt, nullptr);
-            bool rhit = BoxIntersect(nodes[node.LeftFirst + 1].Bounds, ray, &rt, nullptr);
-            lhit = lhit && lt < tmax;
-            rhit = rhit && rt < tmax;
-            if (lhit && rhit) {
-                if (rt < lt) { stack.push_back(node.LeftFirst); stack.push_back(node.LeftFirst + 1); }
-                else { stack.push_back(node.LeftFirst + 1); stack.push_back(node.LeftFirst); }
-            } else if (lhit) stack.push_back(node.LeftFirst);
-            else if (rhit) stack.push_back(node.LeftFirst + 1);
+    int cur = nodes[0].LeftFirst;
+    while (true) {
+        if (st) st->steps++;
+        const Node& L = nodes[cur];
+        const Node& R = nodes[cur + 1];
+        float lt, rt;
+        bool lhit = BoxIntersect(L.Bounds, ray, &lt, nullptr);
+        bool rhit = BoxIntersect(R.Bounds, ray, &rt, nullptr);
+        lhit = lhit && lt < tmax;
+        rhit = rhit && rt < tmax;
+        if (lhit && L.Count > 0) { if (testLeaf(L)) return true; lhit = false; }
+        if (rhit && R.Count > 0) { if (testLeaf(R)) return true; rhit = false; }
+        if (lhit && rhit) {
+            if (rt < lt) { stack.push_back(L.LeftFirst); cur = R.LeftFirst; }
+            else { stack.push_back(R.LeftFirst); cur = L.LeftFirst; }
+        } else if (lhit) cur = L.LeftFirst;
+        else if (rhit) cur = R.LeftFirst;
+        else {
+            if (stack.empty()) break;
+            cur = stack.back();
+            stack.pop_back();
         }
     }
     return false;

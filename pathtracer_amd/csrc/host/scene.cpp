@@ -1,0 +1,523 @@
+// libpt_host.so: host mirror of PathTracer/Scene.cs, Library/Geometry/Mesh.cs + Face.cs, the
+// scene recipe of Game.cs:57-136 and the Camera math of Camera.cs:46-61,89-105, behind the C
+// ABI of include/pt_host.h.  It feeds libpt_hip.so on machines without the C# host.
+//
+// Arithmetic follows the .NET Core 3.1 BCL conventions the reference relies on (row-vector
+// Matrix4x4, Vector3.Dot = (x*x' + y*y') + z*z', true division in Normalize, the seeded
+// Knuth subtractive System.Random); compile with -ffp-contract=off.
+#include "pt_host.h"
+#include "accelerator.hpp"
+#include <cmath>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using namespace pth;
+
+namespace {
+
+thread_local std::string g_error;
+const float kInf = std::numeric_limits<float>::infinity();
+
+// ------------------------------------------------------------------ vectors
+inline Vec3 sub(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3 add(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vec3 scale(float s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline float dot(Vec3 a, Vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline Vec3 cross(Vec3 a, Vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline Vec3 normalize(Vec3 a) { const float l = sqrtf(dot(a, a)); return {a.x / l, a.y / l, a.z / l}; }
+inline float maxNaN(float x, float y) { if (x > y || x != x) return x; if (x == y) return std::signbit(x) ? y : x; return y; }
+inline float minNaN(float x, float y) { if (x < y || x != x) return x; if (x == y) return std::signbit(x) ? x : y; return y; }
+
+// System.Numerics.Matrix4x4, row-major, row-vector convention
+struct Mat4 { float m[16]; };
+Mat4 identity() { Mat4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
+// operator*: each element (a1*b1 + a2*b2) + (a3*b3 + a4*b4), the SSE form of .NET Core 3.x
+Mat4 mul(const Mat4& a, const Mat4& b) {
+    Mat4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            r.m[4 * i + j] = (a.m[4 * i] * b.m[j] + a.m[4 * i + 1] * b.m[4 + j]) + (a.m[4 * i + 2] * b.m[8 + j] + a.m[4 * i + 3] * b.m[12 + j]);
+    return r;
+}
+Mat4 rotationX(float a) { Mat4 r = identity(); const float c = cosf(a), s = sinf(a); r.m[5] = c; r.m[6] = s; r.m[9] = -s; r.m[10] = c; return r; }
+Mat4 rotationY(float a) { Mat4 r = identity(); const float c = cosf(a), s = sinf(a); r.m[0] = c; r.m[2] = -s; r.m[8] = s; r.m[10] = c; return r; }
+Mat4 rotationZ(float a) { Mat4 r = identity(); const float c = cosf(a), s = sinf(a); r.m[0] = c; r.m[1] = s; r.m[4] = -s; r.m[5] = c; return r; }
+Mat4 translation(float x, float y, float z) { Mat4 r = identity(); r.m[12] = x; r.m[13] = y; r.m[14] = z; return r; }
+Mat4 uniformScale(float s) { Mat4 r = identity(); r.m[0] = r.m[5] = r.m[10] = s; return r; }
+// Vector3.Transform / TransformNormal
+Vec3 transformPoint(Vec3 p, const Mat4& t) {
+    return {p.x * t.m[0] + p.y * t.m[4] + p.z * t.m[8] + t.m[12], p.x * t.m[1] + p.y * t.m[5] + p.z * t.m[9] + t.m[13], p.x * t.m[2] + p.y * t.m[6] + p.z * t.m[10] + t.m[14]};
+}
+Vec3 transformNormal(Vec3 n, const Mat4& t) {
+    return {n.x * t.m[0] + n.y * t.m[4] + n.z * t.m[8], n.x * t.m[1] + n.y * t.m[5] + n.z * t.m[9], n.x * t.m[2] + n.y * t.m[6] + n.z * t.m[10]};
+}
+
+// ------------------------------------------------------------ System.Random
+// Seeded constructor of the .NET Core 3.1 BCL: Knuth's subtractive generator.
+class NetRandom {
+public:
+    explicit NetRandom(int32_t seed) {
+        const int32_t big = INT_MAX;
+        int32_t mj = 161803398 - (seed == INT_MIN ? INT_MAX : std::abs(seed));
+        std::memset(table, 0, sizeof(table));
+        table[55] = mj;
+        int32_t mk = 1;
+        for (int i = 1, ii = 0; i < 55; i++) {
+            ii = (ii + 21) % 55;
+            table[ii] = mk;
+            mk = mj - mk;
+            if (mk < 0) mk += big;
+            mj = table[ii];
+        }
+        for (int round = 0; round < 4; round++)
+            for (int i = 1; i <= 55; i++) {
+                table[i] = (int32_t)((uint32_t)table[i] - (uint32_t)table[1 + (i + 30) % 55]);
+                if (table[i] < 0) table[i] += big;
+            }
+        a = 0;
+        b = 21;
+    }
+    int32_t sample() {
+        if (++a >= 56) a = 1;
+        if (++b >= 56) b = 1;
+        int32_t r = table[a] - table[b];
+        if (r == INT_MAX) r--;
+        if (r < 0) r += INT_MAX;
+        table[a] = r;
+        return r;
+    }
+    double nextDouble() { return sample() * (1.0 / INT_MAX); }
+    int32_t next(int32_t maxValue) { return (int32_t)(nextDouble() * maxValue); }
+private:
+    int32_t table[56];
+    int a, b;
+};
+
+// ---------------------------------------------------------------------- mesh
+struct ObjMaterial { Vec3 diffuse{1, 1, 1}, emissive{0, 0, 0}; };
+struct Corner { int p, t, n; };                       // Frame.cs: 0-based, -1 = absent
+struct MeshGroup { ObjMaterial material; std::vector<std::vector<Corner>> faces; };
+struct MeshData {
+    std::vector<Vec3> positions, normals;
+    int texcoords = 0;
+    std::vector<MeshGroup> groups;
+    Vec3 lo{kInf, kInf, kInf}, hi{-kInf, -kInf, -kInf};
+    void addPosition(Vec3 p) {
+        positions.push_back(p);
+        lo = {lo.x < p.x ? lo.x : p.x, lo.y < p.y ? lo.y : p.y, lo.z < p.z ? lo.z : p.z};   // Vector3.Min(min, p)
+        hi = {hi.x > p.x ? hi.x : p.x, hi.y > p.y ? hi.y : p.y, hi.z > p.z ? hi.z : p.z};
+    }
+};
+
+bool isSpace(char c) { return c == ' ' || (c >= 9 && c <= 13); }
+std::string strip(const std::string& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && isSpace(s[a])) a++;
+    while (b > a && isSpace(s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+std::vector<std::string> fields(const std::string& s) {
+    std::vector<std::string> out;
+    std::string cur;
+    for (char c : s) {
+        if (c == ' ' || c == '\t') { if (!cur.empty()) { out.push_back(cur); cur.clear(); } }
+        else cur.push_back(c);
+    }
+    if (!cur.empty()) out.push_back(cur);
+    return out;
+}
+// Mesh.ReadObjLine, Mesh.cs:240-259: key = text before the first blank, arg = the rest
+void keyAndArgument(const std::string& line, std::string& key, std::string& arg) {
+    key.clear();
+    arg.clear();
+    std::string s = line;
+    for (char& c : s) if (c == '\t') c = ' ';
+    s = strip(s);
+    const size_t sp = s.find(' ');
+    if (sp == std::string::npos) return;
+    key = strip(s.substr(0, sp));
+    arg = strip(s.substr(sp + 1));
+}
+Vec3 parseVec3(const std::string& arg) {
+    const auto f = fields(strip(arg));
+    if (f.size() < 3) throw std::runtime_error("Cannot parse .obj file");   // Mesh.cs:280-283
+    return {strtof(f[0].c_str(), nullptr), strtof(f[1].c_str(), nullptr), strtof(f[2].c_str(), nullptr)};
+}
+std::vector<std::string> textLines(const std::string& path) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw std::runtime_error("cannot open " + path);
+    std::stringstream ss;
+    ss << in.rdbuf();
+    std::string text = ss.str();
+    if (text.compare(0, 3, "\xEF\xBB\xBF") == 0) text.erase(0, 3);   // StreamReader eats one byte-order mark
+    std::vector<std::string> lines;
+    std::string cur;
+    for (char c : text) {
+        if (c == '\n') { if (!cur.empty() && cur.back() == '\r') cur.pop_back(); lines.push_back(cur); cur.clear(); }
+        else cur.push_back(c);
+    }
+    if (!cur.empty()) lines.push_back(cur);
+    return lines;
+}
+
+// Mesh.ReadMtlFile, Mesh.cs:181-233 (only the fields the scene uses; Ka also lands in emissive, as there)
+std::map<std::string, ObjMaterial> readMtl(const std::string& path) {
+    std::map<std::string, ObjMaterial> out;
+    std::string name, key, arg;
+    ObjMaterial cur;
+    for (const auto& line : textLines(path)) {
+        keyAndArgument(line, key, arg);
+        if (key == "newmtl") { out[name] = cur; name = arg; cur = ObjMaterial(); }
+        else if (key == "Ka" || key == "Ke") cur.emissive = parseVec3(arg);
+        else if (key == "Kd") cur.diffuse = parseVec3(arg);
+    }
+    out[name] = cur;
+    return out;
+}
+
+// Mesh.LoadFromFile, Mesh.cs:72-179
+MeshData readObj(const std::string& path) {
+    MeshData mesh;
+    std::map<std::string, ObjMaterial> library;
+    ObjMaterial current;
+    std::vector<std::vector<Corner>> pending;
+    const std::string dir = path.substr(0, path.find_last_of('/') + 1);
+    auto closeGroup = [&]() {
+        if (pending.empty()) return;
+        mesh.groups.push_back(MeshGroup{current, pending});
+        pending.clear();
+    };
+    std::string key, arg;
+    for (const auto& line : textLines(path)) {
+        keyAndArgument(line, key, arg);
+        if (key == "v") mesh.addPosition(parseVec3(arg));
+        else if (key == "vt") mesh.texcoords++;
+        else if (key == "vn") mesh.normals.push_back(parseVec3(arg));
+        else if (key == "f") {
+            std::vector<Corner> face;
+            for (const auto& part : fields(strip(arg))) {
+                int idx[3] = {0, 0, 0};
+                int k = 0;
+                size_t from = 0;
+                std::vector<std::string> pieces;
+                for (;;) {
+                    const size_t slash = part.find('/', from);
+                    pieces.push_back(part.substr(from, slash == std::string::npos ? std::string::npos : slash - from));
+                    if (slash == std::string::npos) break;
+                    from = slash + 1;
+                }
+                if (pieces.size() == 1) idx[0] = atoi(pieces[0].c_str());
+                else if (pieces.size() == 2) { idx[0] = atoi(pieces[0].c_str()); idx[1] = atoi(pieces[1].c_str()); }
+                else if (pieces.size() == 3) { idx[0] = atoi(pieces[0].c_str()); if (!pieces[1].empty()) idx[1] = atoi(pieces[1].c_str()); idx[2] = atoi(pieces[2].c_str()); }
+                (void)k;
+                // Mesh.cs:116-118: negative = relative to the end, positive = 1-based, 0 = absent (-1)
+                Corner c;
+                c.p = idx[0] < 0 ? idx[0] + (int)mesh.positions.size() : idx[0] - 1;
+                c.t = idx[1] < 0 ? idx[1] + mesh.texcoords : idx[1] - 1;
+                c.n = idx[2] < 0 ? idx[2] + (int)mesh.normals.size() : idx[2] - 1;
+                face.push_back(c);
+            }
+            pending.push_back(face);
+        } else if (key == "mtllib") {
+            for (auto& kv : readMtl(dir + arg)) library[kv.first] = kv.second;
+        } else if (key == "g") {
+            closeGroup();
+        } else if (key == "usemtl") {
+            closeGroup();
+            auto it = library.find(arg);
+            current = it != library.end() ? it->second : ObjMaterial();
+        }
+    }
+    closeGroup();
+    return mesh;
+}
+
+// Parsed-mesh blob: "PTMESH1\0", u32 count, per mesh { str name, u32 nP, 3f each, u32 nN, 3f each, u32 nT,
+// u32 nGroups, per group { str name, 14 f32 material (ambient, diffuse, specular, emissive, Ns, Tr),
+// u32 nFaces, per face { u32 nCorners, 3 i32 each } } }
+MeshData readBlob(const std::string& path, const std::string& want) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw std::runtime_error("cannot open mesh blob " + path);
+    std::stringstream ss;
+    ss << in.rdbuf();
+    const std::string b = ss.str();
+    size_t at = 8;
+    if (b.size() < 12 || std::memcmp(b.data(), "PTMESH1\0", 8) != 0) throw std::runtime_error(path + " is not a mesh blob");
+    auto u32 = [&]() { if (at + 4 > b.size()) throw std::runtime_error("mesh blob truncated"); uint32_t v; std::memcpy(&v, b.data() + at, 4); at += 4; return v; };
+    auto f32 = [&]() { const uint32_t v = u32(); float f; std::memcpy(&f, &v, 4); return f; };
+    auto str = [&]() { const uint32_t n = u32(); if (at + n > b.size()) throw std::runtime_error("mesh blob truncated"); std::string s = b.substr(at, n); at += n; return s; };
+    const uint32_t count = u32();
+    for (uint32_t m = 0; m < count; m++) {
+        MeshData mesh;
+        const std::string name = str();
+        for (uint32_t i = 0, n = u32(); i < n; i++) { Vec3 p; p.x = f32(); p.y = f32(); p.z = f32(); mesh.addPosition(p); }
+        for (uint32_t i = 0, n = u32(); i < n; i++) { Vec3 p; p.x = f32(); p.y = f32(); p.z = f32(); mesh.normals.push_back(p); }
+        mesh.texcoords = (int)u32();
+        for (uint32_t g = 0, ng = u32(); g < ng; g++) {
+            MeshGroup group;
+            (void)str();
+            float mat[14];
+            for (float& v : mat) v = f32();
+            group.material.diffuse = {mat[3], mat[4], mat[5]};
+            group.material.emissive = {mat[9], mat[10], mat[11]};
+            for (uint32_t f = 0, nf = u32(); f < nf; f++) {
+                std::vector<Corner> face;
+                for (uint32_t k = 0, nk = u32(); k < nk; k++) { Corner c; c.p = (int)u32(); c.t = (int)u32(); c.n = (int)u32(); face.push_back(c); }
+                group.faces.push_back(face);
+            }
+            mesh.groups.push_back(group);
+        }
+        if (name == want) return mesh;
+    }
+    throw std::runtime_error("mesh '" + want + "' is not in " + path);
+}
+
+Vertex vertexOf(Vec3 p, Vec3 n) { Vertex v; std::memset(&v, 0, sizeof(v)); v.Position = p; v.Normal = n; return v; }
+Triangle triangleOf(const Vertex& a, const Vertex& b, const Vertex& c, int material) {
+    Triangle t;
+    std::memset(&t, 0, sizeof(t));
+    t.V1 = a; t.V2 = b; t.V3 = c; t.Material = material;
+    return t;
+}
+bool sameMaterial(const Material& a, const Material& b) {
+    for (int k = 0; k < 4; k++) if (a.Color[k] != b.Color[k] || a.Emissive[k] != b.Emissive[k]) return false;
+    return a.Type == b.Type && a.Index == b.Index && a.Roughness == b.Roughness;
+}
+
+}  // namespace
+
+struct pth_scene {
+    std::string meshSource;
+    std::vector<Material> materials;
+    Accelerator accelerator;
+    std::map<std::string, MeshData> cache;
+
+    const MeshData& mesh(const std::string& name) {
+        auto it = cache.find(name);
+        if (it != cache.end()) return it->second;
+        MeshData m = (!meshSource.empty() && meshSource.back() == '/') ? readObj(meshSource + name + ".obj") : readBlob(meshSource, name);
+        return cache.emplace(name, std::move(m)).first->second;
+    }
+
+    // Scene.GetMaterialIndex, Scene.cs:192-204 (Dictionary keyed by value equality)
+    int materialIndex(const Material& m) {
+        for (size_t i = 0; i < materials.size(); i++) if (sameMaterial(materials[i], m)) return (int)i;
+        materials.push_back(m);
+        return (int)materials.size() - 1;
+    }
+
+    // Scene.LoadGroup + Face.Triangulate + Mesh.GetPosition/GetNormal (Scene.cs:159-174, Face.cs:23-65, Mesh.cs:50-70)
+    void addGroup(const MeshData& mesh, const MeshGroup& group, bool normalized, const Mat4& transform, int material) {
+        const Vec3 extent = sub(mesh.hi, mesh.lo);
+        const float largest = maxNaN(maxNaN(extent.x, extent.y), extent.z);
+        auto corner = [&](const Corner& c) {
+            Vec3 p{0, 0, 0}, n{0, 0, 0};
+            if (c.p >= 0) {
+                p = mesh.positions[c.p];
+                if (normalized) { const Vec3 d = sub(p, mesh.lo); p = {d.x / largest, d.y / largest, d.z / largest}; }
+                p = transformPoint(p, transform);
+            }
+            if (c.n >= 0) n = normalize(transformNormal(mesh.normals[c.n], transform));
+            return vertexOf(p, n);
+        };
+        for (const auto& face : group.faces) {
+            // fan; a, b, c are copies that persist across the fan, so a flat normal written in one
+            // step stays on a (and on b, the previous c) for the next step
+            Vertex a = corner(face[0]), b = corner(face[1]);
+            for (size_t i = 2; i < face.size(); i++) {
+                Vertex c = corner(face[i]);
+                const Vec3 sum = add(add(a.Normal, b.Normal), c.Normal);
+                if (dot(sum, sum) < 0.5f) {
+                    const Vec3 flat = normalize(cross(sub(a.Position, c.Position), sub(b.Position, c.Position)));
+                    a.Normal = b.Normal = c.Normal = flat;
+                }
+                accelerator.AddTriangle(triangleOf(a, b, c, material));
+                b = c;
+            }
+        }
+    }
+
+    void addMesh(const std::string& name, bool normalized, const Mat4& transform, const Material* material) {
+        const MeshData& m = mesh(name);
+        if (material) {
+            const int id = materialIndex(*material);
+            for (const auto& g : m.groups) addGroup(m, g, normalized, transform, id);
+        } else {
+            for (const auto& g : m.groups) {
+                Material mat;
+                std::memset(&mat, 0, sizeof(mat));
+                mat.Color[0] = g.material.diffuse.x; mat.Color[1] = g.material.diffuse.y; mat.Color[2] = g.material.diffuse.z;
+                mat.Emissive[0] = g.material.emissive.x; mat.Emissive[1] = g.material.emissive.y; mat.Emissive[2] = g.material.emissive.z;
+                addGroup(m, g, normalized, transform, materialIndex(mat));
+            }
+        }
+    }
+
+    // Scene.GenerateTiledFoloor, Scene.cs:87-120
+    void tiledFloor(const Material& a, const Material& b) {
+        const int ia = materialIndex(a), ib = materialIndex(b);
+        const Vec3 up{0, 1, 0};
+        for (int x = -100; x < 99; x++)
+            for (int y = -100; y < 99; y++) {
+                const int mat = ((x & 1) ^ (y & 1)) == 0 ? ia : ib;
+                const Vertex v4 = vertexOf({(float)x, 0, (float)y}, up), v3 = vertexOf({(float)(x + 1), 0, (float)y}, up);
+                const Vertex v2 = vertexOf({(float)(x + 1), 0, (float)(y + 1)}, up), v1 = vertexOf({(float)x, 0, (float)(y + 1)}, up);
+                accelerator.AddTriangle(triangleOf(v1, v2, v3, mat));
+                accelerator.AddTriangle(triangleOf(v3, v4, v1, mat));
+            }
+    }
+
+    // Game.InitializeScene, Game.cs:66-136
+    void bundledScene(int seed) {
+        Material tile;
+        std::memset(&tile, 0, sizeof(tile));
+        tile.Color[0] = 0.7f; tile.Color[1] = 0.7f; tile.Color[2] = 0.9f;
+        tile.Type = 3;
+        Material tile1 = tile, tile2 = tile;
+        tile1.Roughness = 0.1f;
+        tile2.Roughness = 0.16f;
+        addMesh("light", false, identity(), nullptr);
+        tiledFloor(tile1, tile2);
+        NetRandom rng(seed);
+        const float pi = 3.14159274f;
+        static const char* const shapes[5] = {"cube", "cube", "sphere", "sphere", "bunny"};
+        for (int i = 0; i < 60; i++) {
+            Material m;
+            std::memset(&m, 0, sizeof(m));
+            for (int k = 0; k < 3; k++) m.Color[k] = (float)rng.nextDouble();
+            if (rng.next(100) > 90)
+                for (int k = 0; k < 4; k++) m.Emissive[k] = (k < 3 ? (float)rng.nextDouble() : 0.0f) * 8.0f;
+            m.Index = 1.4f;
+            m.Type = rng.next(4);
+            m.Roughness = (float)rng.nextDouble();
+            const float x = (float)rng.nextDouble() * 12 - 6;
+            const float y = (float)rng.nextDouble() * 5 + 1;
+            const float z = (float)rng.nextDouble() * 12 - 6;
+            const float ra = (float)rng.nextDouble() * pi, rb = (float)rng.nextDouble() * pi, rc = (float)rng.nextDouble() * pi;
+            const float s = (float)rng.nextDouble() + 0.5f;
+            Mat4 t = identity();
+            t = mul(t, rotationX(ra));
+            t = mul(t, rotationY(rb));
+            t = mul(t, rotationZ(rc));
+            t = mul(t, translation(x, y, z));
+            t = mul(t, uniformScale(s));
+            addMesh(shapes[rng.next(5)], true, t, &m);
+        }
+    }
+
+    // Random triangle soup: xorshift32 stream, 12 draws per triangle (centre, three offsets)
+    void soup(int n, uint32_t seed) {
+        Material grey, lamp;
+        std::memset(&grey, 0, sizeof(grey));
+        std::memset(&lamp, 0, sizeof(lamp));
+        for (int k = 0; k < 3; k++) { grey.Color[k] = 0.7f; lamp.Color[k] = 1.0f; lamp.Emissive[k] = 20.0f; }
+        const int g = materialIndex(grey), l = materialIndex(lamp);
+        const Vec3 down{0, -1, 0};
+        const Vertex q1 = vertexOf({-30, 60, -30}, down), q2 = vertexOf({-30, 60, 30}, down), q3 = vertexOf({30, 60, 30}, down), q4 = vertexOf({30, 60, -30}, down);
+        accelerator.AddTriangle(triangleOf(q1, q2, q3, l));
+        accelerator.AddTriangle(triangleOf(q3, q4, q1, l));
+        uint32_t state = seed;
+        auto uniform = [&state]() { state ^= state << 13; state ^= state >> 17; state ^= state << 5; return (float)state * 2.3283064365386963e-10f; };
+        for (int i = 0; i < n - 2; i++) {
+            Vec3 c;
+            c.x = uniform() * 100.0f - 50.0f; c.y = uniform() * 100.0f - 50.0f; c.z = uniform() * 100.0f - 50.0f;
+            Vec3 p[3];
+            for (auto& q : p) { Vec3 e; e.x = uniform() - 0.5f; e.y = uniform() - 0.5f; e.z = uniform() - 0.5f; q = add(c, e); }
+            const Vec3 nrm = normalize(cross(sub(p[1], p[0]), sub(p[2], p[0])));
+            accelerator.AddTriangle(triangleOf(vertexOf(p[0], nrm), vertexOf(p[1], nrm), vertexOf(p[2], nrm), g));
+        }
+    }
+};
+
+#define PTH_GUARD(...) try { __VA_ARGS__; return 0; } catch (const std::exception& e) { g_error = e.what(); return -1; }
+
+extern "C" {
+
+const char* pth_last_error(void) { return g_error.c_str(); }
+
+pth_scene* pth_scene_create(const char* mesh_source) {
+    pth_scene* s = new pth_scene();
+    s->meshSource = mesh_source ? mesh_source : "";
+    return s;
+}
+void pth_scene_destroy(pth_scene* s) { delete s; }
+
+int pth_scene_clear(pth_scene* s) { PTH_GUARD(s->materials.clear(); s->accelerator.Clear()) }
+
+int pth_scene_add_mesh(pth_scene* s, const char* name, int normalized, const float* matrix16, const void* material48) {
+    PTH_GUARD(
+        Mat4 t = identity();
+        if (matrix16) std::memcpy(t.m, matrix16, 64);
+        Material m;
+        if (material48) std::memcpy(&m, material48, 48);
+        s->addMesh(name, normalized != 0, t, material48 ? &m : nullptr))
+}
+
+int pth_scene_generate_tiled_floor(pth_scene* s, const void* a48, const void* b48) {
+    PTH_GUARD(Material a; Material b; std::memcpy(&a, a48, 48); std::memcpy(&b, b48, 48); s->tiledFloor(a, b))
+}
+
+int pth_scene_get_material_index(pth_scene* s, const void* material48, int32_t* index) {
+    PTH_GUARD(Material m; std::memcpy(&m, material48, 48); *index = s->materialIndex(m))
+}
+
+int pth_scene_add_triangles(pth_scene* s, const void* triangles112, int32_t n) {
+    PTH_GUARD(const Triangle* t = (const Triangle*)triangles112; for (int i = 0; i < n; i++) s->accelerator.AddTriangle(t[i]))
+}
+
+int pth_scene_initialize(pth_scene* s, int32_t seed) { PTH_GUARD(s->bundledScene(seed)) }
+
+int pth_scene_generate_soup(pth_scene* s, int32_t n, uint32_t seed) { PTH_GUARD(if (n < 2) throw std::runtime_error("soup needs at least 2 triangles"); s->soup(n, seed)) }
+
+int pth_scene_build(pth_scene* s, int32_t threads) { PTH_GUARD(s->accelerator.Build(threads)) }
+
+int pth_scene_counts(pth_scene* s, int32_t* out4) {
+    PTH_GUARD(out4[0] = (int32_t)s->materials.size(); out4[1] = (int32_t)s->accelerator.triangles.size();
+              out4[2] = (int32_t)s->accelerator.nodes.size(); out4[3] = s->accelerator.Depth())
+}
+
+int pth_scene_arrays(pth_scene* s, const void** materials48, const void** triangles112, const void** nodes32) {
+    PTH_GUARD(if (materials48) *materials48 = s->materials.data(); if (triangles112) *triangles112 = s->accelerator.triangles.data();
+              if (nodes32) *nodes32 = s->accelerator.nodes.data())
+}
+
+// Camera.Update first half, Camera.cs:48-50
+int pth_camera_basis(const float* position3, const float* target3, float* forward3, float* right3, float* up3) {
+    PTH_GUARD(
+        const Vec3 pos{position3[0], position3[1], position3[2]}; const Vec3 tgt{target3[0], target3[1], target3[2]};
+        const Vec3 f = normalize(sub(tgt, pos));
+        const Vec3 r = normalize(cross(Vec3{0, 1, 0}, f));
+        const Vec3 u = normalize(cross(f, r));
+        forward3[0] = f.x; forward3[1] = f.y; forward3[2] = f.z;
+        right3[0] = r.x; right3[1] = r.y; right3[2] = r.z;
+        up3[0] = u.x; up3[1] = u.y; up3[2] = u.z)
+}
+
+// Camera.GetFocalDistance's Min(distance, 20) and the second half of Camera.Update, Camera.cs:51-58,94; SetUniform, Camera.cs:97-105
+int pth_camera_state(const float* position3, const float* forward3, const float* right3, const float* up3,
+                     float hit_distance, int32_t width, int32_t height, void* camera_state96, float* focal_out) {
+    PTH_GUARD(
+        const Vec3 pos{position3[0], position3[1], position3[2]}; const Vec3 f{forward3[0], forward3[1], forward3[2]};
+        const Vec3 r{right3[0], right3[1], right3[2]}; const Vec3 u{up3[0], up3[1], up3[2]};
+        const float focal = minNaN(hit_distance, 20.0f);
+        const float ar = (float)width / (float)height;
+        const Vec3 c = add(pos, scale(focal, f));
+        const Vec3 halfRight = scale(0.5f * focal * ar, r); const Vec3 halfUp = scale(0.5f * focal, u);
+        const Vec3 p1 = add(sub(c, halfRight), halfUp); const Vec3 p2 = add(add(c, halfRight), halfUp); const Vec3 p3 = sub(sub(c, halfRight), halfUp);
+        float* o = (float*)camera_state96;
+        std::memset(o, 0, 96);
+        const Vec3 cols[6] = {p1, p2, p3, pos, r, u};
+        for (int k = 0; k < 6; k++) { o[4 * k] = cols[k].x; o[4 * k + 1] = cols[k].y; o[4 * k + 2] = cols[k].z; }
+        if (focal_out) *focal_out = focal)
+}
+
+}  // extern "C"

@@ -1,0 +1,601 @@
+// libpt_hip.so — C ABI over the wavefront kernels (see include/pt_hip.h).
+// Host side: validation and device repack of the uploaded scene, queue allocation, the stage
+// schedule of one render call (all launches enqueued on one stream, no host round trip per
+// bounce), statistics.
+#include "pt_hip.h"
+#include "pt_kernels.hpp"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <algorithm>
+
+namespace {
+
+struct HostNode { float mn[3], mx[3]; int32_t leftFirst, count; };
+struct HostVertex { float pos[3], pad0, nrm[3], pad1; };
+struct HostTriangle { HostVertex v[3]; int32_t material; int32_t pad[3]; };
+struct HostMaterial { float color[4], emissive[4]; int32_t type; float index, roughness; int32_t pad; };
+struct HostRenderState { int32_t width, height, pad[2]; float sky[4]; };
+struct HostCamera { float p1[3], _0, p2[3], _1, p3[3], _2, pos[3], _3, right[3], _4, up[3], _5; };
+struct HostFrameState { int32_t frames, samples; float focal; int32_t pad; HostCamera cam; };
+static_assert(sizeof(HostNode) == 32 && sizeof(HostTriangle) == 112 && sizeof(HostMaterial) == 48, "host layouts");
+static_assert(sizeof(HostRenderState) == 32 && sizeof(HostFrameState) == 112, "host layouts");
+
+std::string g_err;   // errors without a context
+
+}  // namespace
+
+struct pt_ctx {
+    pt_config cfg;
+    std::string err;
+    hipStream_t stream = nullptr;
+    int num_cu = 256;
+    // scene
+    DevScene sc{};
+    void *d_pairs = nullptr, *d_hot = nullptr, *d_cold = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+    bool has_scene = false;
+    // image / queues
+    int width = 0, height = 0;
+    uint32_t groups = 0, local_groups = 0, slots = 0, slots_padded = 0;
+    uint32_t capacity = 0, batch = 0;   // queue capacity in paths, samples per batch
+    Queues q{};
+    std::vector<void*> qmem;
+    float4* d_sum = nullptr;
+    float4* d_image = nullptr;
+    Ctl* d_ctl = nullptr;
+    HostRenderState rs{};
+    bool has_rs = false;
+    uint32_t samples_accumulated = 0;
+    // timing
+    struct Span { hipEvent_t a, b; int stage; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool render_pending = false;
+    pt_stats host_stats{};
+    int grid_extend = 0, grid_connect = 0, grid_shade = 0;
+};
+
+#define FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); if (ctx) (ctx)->err = _b; else g_err = _b; return (code); } while (0)
+#define HIPCHECK(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
+    FAIL(ctx, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
+
+namespace {
+
+void freeQueues(pt_ctx* c) {
+    for (void* p : c->qmem) (void)hipFree(p);
+    c->qmem.clear();
+    c->q = Queues{};
+    if (c->d_sum) { (void)hipFree(c->d_sum); c->d_sum = nullptr; }
+    if (c->d_image) { (void)hipFree(c->d_image); c->d_image = nullptr; }
+    c->capacity = 0;
+}
+
+void freeScene(pt_ctx* c) {
+    void** ps[] = {&c->d_pairs, &c->d_hot, &c->d_cold, &c->d_mats, &c->d_lights};
+    for (void** p : ps) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
+    c->has_scene = false;
+    c->sc = DevScene{};
+}
+
+int allocQueues(pt_ctx* c, uint32_t capacity) {
+    for (void* p : c->qmem) (void)hipFree(p);
+    c->qmem.clear();
+    float4** cols[] = {&c->q.o[0], &c->q.o[1], &c->q.d[0], &c->q.d[1], &c->q.T[0], &c->q.T[1], &c->q.hit, &c->q.so, &c->q.sd, &c->q.sc, &c->q.plane};
+    for (float4** col : cols) {
+        void* p = nullptr;
+        HIPCHECK(c, hipMalloc(&p, (size_t)capacity * sizeof(float4)));
+        c->qmem.push_back(p);
+        *col = (float4*)p;
+    }
+    c->capacity = capacity;
+    return PT_OK;
+}
+
+uint32_t chooseBatch(const pt_ctx* c, uint32_t spp) {
+    uint32_t want = (uint32_t)c->cfg.samples_per_batch;
+    if (want == 0) {
+        // enough paths per launch to fill 256 CUs x 32 waves several times over
+        const uint32_t target = 4u << 20;
+        want = std::max(1u, target / std::max(1u, c->slots));
+        want = std::min(want, 64u);
+    }
+    return std::max(1u, std::min(want, std::max(1u, spp)));
+}
+
+hipEvent_t getEvent(pt_ctx* c) {
+    if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct StageTimer {
+    pt_ctx* c; int stage; hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(pt_ctx* ctx, int s) : c(ctx), stage(s) {
+        if (c->cfg.stage_timing) { a = getEvent(c); b = getEvent(c); if (a) (void)hipEventRecord(a, c->stream); }
+    }
+    ~StageTimer() {
+        if (a && b) { (void)hipEventRecord(b, c->stream); c->spans.push_back({a, b, stage}); }
+    }
+};
+
+void collectSpans(pt_ctx* c) {
+    for (auto& s : c->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            float* dst[] = {&c->host_stats.ms_generate, &c->host_stats.ms_extend, &c->host_stats.ms_shade, &c->host_stats.ms_connect};
+            *dst[s.stage] += ms;
+        }
+        c->pool.push_back(s.a);
+        c->pool.push_back(s.b);
+    }
+    c->spans.clear();
+}
+
+// Validates the host's Node[] (Accelerator.cs:113-177 output shape) so that no kernel can
+// index out of bounds, and returns the tree depth.
+int validateBvh(pt_ctx* c, const HostNode* nodes, int n_nodes, int n_tris, int* depth_out) {
+    if (n_nodes == 0) { *depth_out = 0; return PT_OK; }
+    if ((n_nodes & 1) == 0) FAIL(c, PT_E_BAD_BVH, "node count %d is even: nodes are a root plus sibling pairs", n_nodes);
+    std::vector<int> depth(n_nodes, 0);
+    std::vector<uint8_t> seen(n_nodes, 0);
+    depth[0] = 1;
+    seen[0] = 1;
+    int maxDepth = 1;
+    long long leafTris = 0;
+    for (int i = 0; i < n_nodes; i++) {
+        const HostNode& nd = nodes[i];
+        if (!seen[i]) FAIL(c, PT_E_BAD_BVH, "node %d is not referenced by an earlier node", i);
+        if (nd.count > 0) {
+            if (nd.leftFirst < 0 || (long long)nd.leftFirst + nd.count > n_tris) FAIL(c, PT_E_BAD_BVH, "leaf %d references triangles [%d,%d) of %d", i, nd.leftFirst, nd.leftFirst + nd.count, n_tris);
+            leafTris += nd.count;
+        } else {
+            const int l = nd.leftFirst;
+            if (l <= i || (l & 1) == 0 || l + 1 >= n_nodes) FAIL(c, PT_E_BAD_BVH, "interior node %d has children at %d (need odd, > parent, < %d)", i, l, n_nodes - 1);
+            if (seen[l] || seen[l + 1]) FAIL(c, PT_E_BAD_BVH, "node pair %d is referenced twice", l);
+            seen[l] = seen[l + 1] = 1;
+            depth[l] = depth[l + 1] = depth[i] + 1;
+            maxDepth = std::max(maxDepth, depth[i] + 1);
+        }
+    }
+    if (leafTris != n_tris) FAIL(c, PT_E_BAD_BVH, "leaves cover %lld triangles, %d uploaded", leafTris, n_tris);
+    *depth_out = maxDepth;
+    return PT_OK;
+}
+
+int launchGrid(uint32_t n) { return (int)((n + PT_BLOCK - 1) / PT_BLOCK); }
+
+}  // namespace
+
+extern "C" {
+
+int pt_default_config(pt_config* cfg) {
+    if (!cfg) return PT_E_INVALID_ARG;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (int32_t)sizeof(pt_config);
+    cfg->tile_world = 1;
+    return PT_OK;
+}
+
+const char* pt_last_error(pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int pt_create(const pt_config* cfg, pt_ctx** out) {
+    if (!cfg || !out) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(pt_config)) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: struct_size %d, expected %zu", cfg->struct_size, sizeof(pt_config));
+    if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: tile rank %d of %d", cfg->tile_rank, cfg->tile_world);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) FAIL((pt_ctx*)nullptr, PT_E_NO_DEVICE, "pt_create: no HIP device");
+    if (cfg->device < 0 || cfg->device >= ndev) FAIL((pt_ctx*)nullptr, PT_E_NO_DEVICE, "pt_create: device %d of %d", cfg->device, ndev);
+    pt_ctx* c = new pt_ctx();
+    c->cfg = *cfg;
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctl, sizeof(Ctl));
+    if (e == hipSuccess) e = hipMemset(c->d_ctl, 0, sizeof(Ctl));
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, cfg->device);
+    if (e != hipSuccess) {
+        g_err = std::string("pt_create: ") + hipGetErrorString(e);
+        delete c;
+        return PT_E_HIP;
+    }
+    c->num_cu = prop.multiProcessorCount;
+    int perCu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_extend<false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    c->grid_extend = c->num_cu * perCu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_connect<false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    c->grid_connect = c->num_cu * perCu;
+    c->grid_shade = c->num_cu * 8;
+    *out = c;
+    return PT_OK;
+}
+
+int pt_destroy(pt_ctx* c) {
+    if (!c) return PT_OK;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    freeQueues(c);
+    freeScene(c);
+    if (c->d_ctl) (void)hipFree(c->d_ctl);
+    for (auto& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PT_OK;
+}
+
+int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
+    if (!c) return PT_E_INVALID_ARG;
+    switch (key) {
+        case PT_OPT_NEE: c->cfg.nee = value ? 1 : 0; break;
+        case PT_OPT_RNG_MODE: if (value != 0 && value != 1) FAIL(c, PT_E_INVALID_ARG, "rng_mode %d", value); c->cfg.rng_mode = value; break;
+        case PT_OPT_TRAVERSAL_STATS: c->cfg.traversal_stats = value ? 1 : 0; break;
+        case PT_OPT_STAGE_TIMING: c->cfg.stage_timing = value ? 1 : 0; break;
+        case PT_OPT_SAMPLES_PER_BATCH: if (value < 0) FAIL(c, PT_E_INVALID_ARG, "samples_per_batch %d", value); c->cfg.samples_per_batch = value; break;
+        default: FAIL(c, PT_E_INVALID_ARG, "unknown option %d", key);
+    }
+    return PT_OK;
+}
+
+int pt_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles, int32_t n_tri, const void* nodes, int32_t n_nodes) {
+    if (!c) return PT_E_INVALID_ARG;
+    if (n_mat < 0 || n_tri < 0 || n_nodes < 0 || (n_mat && !materials) || (n_tri && !triangles) || (n_nodes && !nodes)) FAIL(c, PT_E_INVALID_ARG, "pt_upload_scene: bad counts or null arrays");
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    const HostNode* hn = (const HostNode*)nodes;
+    const HostTriangle* ht = (const HostTriangle*)triangles;
+    const HostMaterial* hm = (const HostMaterial*)materials;
+    if (n_tri == 0) n_nodes = 0;   // Accelerator.Build on an empty scene leaves a childless root (Accelerator.cs:120-125)
+    int depth = 0;
+    int rc = validateBvh(c, hn, n_nodes, n_tri, &depth);
+    if (rc != PT_OK) return rc;
+    if (depth > PT_STACK_TOTAL) FAIL(c, PT_E_BAD_BVH, "BVH depth %d exceeds the traversal stack (%d)", depth, PT_STACK_TOTAL);
+    for (int i = 0; i < n_tri; i++)
+        if (ht[i].material < 0 || ht[i].material >= n_mat) FAIL(c, PT_E_INVALID_ARG, "triangle %d has material %d of %d", i, ht[i].material, n_mat);
+
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    freeScene(c);
+
+    // ---- repack
+    const int n_pairs = n_nodes > 0 ? (n_nodes - 1) / 2 : 0;
+    std::vector<float4> hot((size_t)n_tri * 3), cold((size_t)n_tri * 3), lights;
+    float lightSum = 0.0f;
+    for (int i = 0; i < n_tri; i++) {
+        const HostTriangle& t = ht[i];
+        const float* a = t.v[0].pos; const float* b = t.v[1].pos; const float* cc = t.v[2].pos;
+        float mbits;
+        memcpy(&mbits, &t.material, 4);
+        const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};     // Triangle.cs:17
+        const float e2[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]};  // Triangle.cs:18
+        hot[3 * (size_t)i] = make_float4(a[0], a[1], a[2], mbits);
+        hot[3 * (size_t)i + 1] = make_float4(e1[0], e1[1], e1[2], 0.0f);
+        hot[3 * (size_t)i + 2] = make_float4(e2[0], e2[1], e2[2], 0.0f);
+        for (int k = 0; k < 3; k++) cold[3 * (size_t)i + k] = make_float4(t.v[k].nrm[0], t.v[k].nrm[1], t.v[k].nrm[2], 0.0f);
+        const HostMaterial& m = hm[t.material];
+        if (m.emissive[0] > 0 || m.emissive[1] > 0 || m.emissive[2] > 0) {   // shade.glsl:366
+            const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+            const float area = 0.5f * sqrtf((nx * nx + ny * ny) + nz * nz);
+            lightSum = lightSum + area;
+            lights.push_back(make_float4(a[0], a[1], a[2], lightSum));
+            lights.push_back(make_float4(b[0], b[1], b[2], mbits));
+            lights.push_back(make_float4(cc[0], cc[1], cc[2], 0.0f));
+        }
+    }
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> int {
+        if (bytes == 0) { *dst = nullptr; return PT_OK; }
+        HIPCHECK(c, hipMalloc(dst, bytes));
+        HIPCHECK(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return PT_OK;
+    };
+    // sibling pair k = nodes[2k+1], nodes[2k+2]: the node array shifted by one node lands on 64-byte lines
+    if ((rc = upload(&c->d_pairs, n_pairs ? hn + 1 : nullptr, (size_t)n_pairs * 64)) != PT_OK) return rc;
+    if ((rc = upload(&c->d_hot, hot.data(), hot.size() * sizeof(float4))) != PT_OK) return rc;
+    if ((rc = upload(&c->d_cold, cold.data(), cold.size() * sizeof(float4))) != PT_OK) return rc;
+    if ((rc = upload(&c->d_mats, hm, (size_t)n_mat * 48)) != PT_OK) return rc;
+    if ((rc = upload(&c->d_lights, lights.data(), lights.size() * sizeof(float4))) != PT_OK) return rc;
+
+    DevScene& sc = c->sc;
+    sc.pairs = (const float4*)c->d_pairs;
+    sc.tri_hot = (const float4*)c->d_hot;
+    sc.tri_cold = (const float4*)c->d_cold;
+    sc.mats = (const float4*)c->d_mats;
+    sc.lights = (const float4*)c->d_lights;
+    sc.n_nodes = n_nodes;
+    sc.n_tris = n_tri;
+    sc.n_lights = (int32_t)(lights.size() / 3);
+    sc.light_total = lightSum;
+    if (n_nodes > 0) {
+        for (int k = 0; k < 3; k++) { sc.root_min[k] = hn[0].mn[k]; sc.root_max[k] = hn[0].mx[k]; }
+        sc.root_left = hn[0].leftFirst;
+        sc.root_count = hn[0].count;
+    }
+    c->has_scene = true;
+    return PT_OK;
+}
+
+int pt_resize(pt_ctx* c, int32_t width, int32_t height) {
+    if (!c) return PT_E_INVALID_ARG;
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28)) FAIL(c, PT_E_INVALID_ARG, "pt_resize: %d x %d", width, height);
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    freeQueues(c);
+    c->width = width;
+    c->height = height;
+    c->groups = (uint32_t)((width + 7) / 8) * (uint32_t)((height + 7) / 8);
+    const uint32_t world = (uint32_t)c->cfg.tile_world, rank = (uint32_t)c->cfg.tile_rank;
+    c->local_groups = (c->groups + world - 1 - rank) / world;
+    c->slots = c->local_groups * 64u;
+    c->slots_padded = ((c->groups + world - 1) / world) * 64u;   // the same on every rank
+    HIPCHECK(c, hipMalloc((void**)&c->d_sum, (size_t)std::max(1u, c->slots_padded) * sizeof(float4)));
+    HIPCHECK(c, hipMalloc((void**)&c->d_image, (size_t)width * height * sizeof(float4)));
+    HIPCHECK(c, hipMemset(c->d_sum, 0, (size_t)std::max(1u, c->slots_padded) * sizeof(float4)));
+    c->samples_accumulated = 0;
+    c->has_rs = false;
+    return PT_OK;
+}
+
+int pt_set_render_state(pt_ctx* c, const void* rs32) {
+    if (!c || !rs32) return PT_E_INVALID_ARG;
+    HostRenderState rs;
+    memcpy(&rs, rs32, sizeof(rs));
+    if (rs.width != c->width || rs.height != c->height) FAIL(c, PT_E_INVALID_ARG, "render state is %d x %d, pt_resize was %d x %d", rs.width, rs.height, c->width, c->height);
+    c->rs = rs;
+    c->has_rs = true;
+    return PT_OK;
+}
+
+int pt_reset_accumulation(pt_ctx* c) {
+    if (!c) return PT_E_INVALID_ARG;
+    if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_reset_accumulation before pt_resize");
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    HIPCHECK(c, hipMemsetAsync(c->d_sum, 0, (size_t)std::max(1u, c->slots_padded) * sizeof(float4), c->stream));
+    c->samples_accumulated = 0;
+    return PT_OK;
+}
+
+static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32_t max_bounces, bool generate_only) {
+    RenderParams rp{};
+    rp.width = c->width;
+    rp.height = c->height;
+    memcpy(rp.sky, c->rs.sky, 16);
+    memcpy(rp.p1, fs.cam.p1, 12); memcpy(rp.p2, fs.cam.p2, 12); memcpy(rp.p3, fs.cam.p3, 12);
+    memcpy(rp.pos, fs.cam.pos, 12); memcpy(rp.right, fs.cam.right, 12); memcpy(rp.up, fs.cam.up, 12);
+    rp.slots = c->slots;
+    rp.rank = c->cfg.tile_rank;
+    rp.world = c->cfg.tile_world;
+    rp.rng_mode = c->cfg.rng_mode;
+    rp.nee = c->cfg.nee;
+    const bool stats = c->cfg.traversal_stats != 0;
+
+    const uint32_t batch = generate_only ? 1u : chooseBatch(c, (uint32_t)spp);
+    const uint32_t need = c->slots * batch;
+    if (need > c->capacity) {
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        int rc = allocQueues(c, need);
+        if (rc != PT_OK) return rc;
+    }
+    if (c->slots == 0) return PT_OK;
+
+    for (uint32_t s0 = 0; s0 < (uint32_t)spp; s0 += batch) {
+        const uint32_t ns = std::min(batch, (uint32_t)spp - s0);
+        const uint32_t total = c->slots * ns;
+        rp.frames0 = (uint32_t)fs.frames + s0;
+        rp.samples = ns;
+        HIPCHECK(c, hipMemsetAsync(c->q.plane, 0, (size_t)total * sizeof(float4), c->stream));
+        hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, 0ull);
+        {
+            StageTimer t(c, 0);
+            hipLaunchKernelGGL(k_generate, dim3(launchGrid(total)), dim3(PT_BLOCK), 0, c->stream, rp, c->q, c->d_ctl);
+            c->host_stats.generate_launches++;
+        }
+        if (generate_only) break;
+        int cur = 0;
+        for (int b = 0; b < max_bounces; b++) {
+            rp.bounce = b;
+            rp.last_bounce = (b == max_bounces - 1) ? 1 : 0;
+            {
+                StageTimer t(c, 1);
+                if (stats) hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
+                else hipLaunchKernelGGL(k_extend<false>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
+                c->host_stats.extend_launches++;
+            }
+            {
+                StageTimer t(c, 2);
+                hipLaunchKernelGGL(k_shade, dim3(c->grid_shade), dim3(PT_BLOCK), 0, c->stream, c->sc, rp, c->q, c->d_ctl, cur);
+                c->host_stats.shade_launches++;
+            }
+            if (rp.nee && c->sc.n_lights > 0) {
+                StageTimer t(c, 3);
+                if (stats) hipLaunchKernelGGL(k_connect<true>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
+                else hipLaunchKernelGGL(k_connect<false>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
+                c->host_stats.connect_launches++;
+            }
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL(k_resolve, dim3(launchGrid(c->slots)), dim3(PT_BLOCK), 0, c->stream, c->d_sum, (const float4*)c->q.plane, c->slots, ns);
+        hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, (unsigned long long)total);
+    }
+    HIPCHECK(c, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32_t max_bounces) {
+    if (!c || !frame_state112) return PT_E_INVALID_ARG;
+    if (spp < 1 || max_bounces < 1 || max_bounces > 64) FAIL(c, PT_E_INVALID_ARG, "pt_render: spp %d, max_bounces %d", spp, max_bounces);
+    if (!c->has_scene) FAIL(c, PT_E_STATE, "pt_render before pt_upload_scene");
+    if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_render before pt_resize");
+    if (!c->has_rs) FAIL(c, PT_E_STATE, "pt_render before pt_set_render_state");
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    HostFrameState fs;
+    memcpy(&fs, frame_state112, sizeof(fs));
+    HIPCHECK(c, hipEventRecord(c->ev_begin, c->stream));
+    int rc = renderBatches(c, fs, spp, max_bounces, false);
+    if (rc != PT_OK) return rc;
+    HIPCHECK(c, hipEventRecord(c->ev_end, c->stream));
+    c->render_pending = true;
+    c->samples_accumulated += (uint32_t)spp;
+    return PT_OK;
+}
+
+int pt_synchronize(pt_ctx* c) {
+    if (!c) return PT_E_INVALID_ARG;
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (c->render_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->host_stats.ms_render = ms;
+        c->render_pending = false;
+    }
+    collectSpans(c);
+    return PT_OK;
+}
+
+int pt_stream(pt_ctx* c, void** stream) {
+    if (!c || !stream) return PT_E_INVALID_ARG;
+    *stream = (void*)c->stream;
+    return PT_OK;
+}
+
+int pt_accum_device(pt_ctx* c, void** device_ptr, uint64_t* n_slots_padded, uint32_t* samples) {
+    if (!c) return PT_E_INVALID_ARG;
+    if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_accum_device before pt_resize");
+    if (device_ptr) *device_ptr = c->d_sum;
+    if (n_slots_padded) *n_slots_padded = c->slots_padded;
+    if (samples) *samples = c->samples_accumulated;
+    return PT_OK;
+}
+
+int pt_assemble_tiles(pt_ctx* c, const void* gathered_device, int32_t world, uint32_t samples, float* rgba_host) {
+    if (!c || !gathered_device || !rgba_host) return PT_E_INVALID_ARG;
+    if (world != c->cfg.tile_world) FAIL(c, PT_E_INVALID_ARG, "pt_assemble_tiles: world %d, context was created for %d", world, c->cfg.tile_world);
+    if (!c->d_image) FAIL(c, PT_E_STATE, "pt_assemble_tiles before pt_resize");
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    hipLaunchKernelGGL(k_assemble, dim3(launchGrid(c->groups * 64u)), dim3(PT_BLOCK), 0, c->stream, (const float4*)gathered_device, c->slots_padded, world,
+                       c->width, c->height, (float)samples, c->d_image);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(rgba_host, c->d_image, (size_t)c->width * c->height * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    return pt_synchronize(c);
+}
+
+int pt_read_image(pt_ctx* c, float* rgba) {
+    if (!c || !rgba) return PT_E_INVALID_ARG;
+    if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_read_image before pt_resize");
+    if (c->cfg.tile_world != 1) FAIL(c, PT_E_STATE, "pt_read_image on a tile-sharded context: gather with pt_accum_device + pt_assemble_tiles");
+    return pt_assemble_tiles(c, c->d_sum, 1, std::max(1u, c->samples_accumulated), rgba);
+}
+
+static int traceCommon(pt_ctx* c, bool anyhit, const float* o_d, const float* tmax, int32_t n, int32_t* tri, float* t, float* uv, uint8_t* occ) {
+    if (!c || n < 0 || (n && !o_d)) return PT_E_INVALID_ARG;
+    if (!c->has_scene) FAIL(c, PT_E_STATE, "trace before pt_upload_scene");
+    if (n == 0) return PT_OK;
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    float *d_rays = nullptr, *d_tmax = nullptr, *d_t = nullptr, *d_uv = nullptr;
+    int32_t* d_tri = nullptr;
+    uint8_t* d_occ = nullptr;
+    int rc = PT_OK;
+    auto cleanup = [&]() { (void)hipFree(d_rays); (void)hipFree(d_tmax); (void)hipFree(d_t); (void)hipFree(d_uv); (void)hipFree(d_tri); (void)hipFree(d_occ); };
+#define TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); FAIL(c, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s", #call, hipGetErrorString(_e)); } } while (0)
+    TRY(hipMalloc((void**)&d_rays, (size_t)n * 24));
+    TRY(hipMemcpyAsync(d_rays, o_d, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    if (anyhit) {
+        TRY(hipMalloc((void**)&d_tmax, (size_t)n * 4));
+        TRY(hipMalloc((void**)&d_occ, (size_t)n));
+        TRY(hipMemcpyAsync(d_tmax, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_trace<true>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, d_rays, d_tmax, n, nullptr, nullptr, nullptr, d_occ, c->d_ctl);
+        TRY(hipGetLastError());
+        TRY(hipMemcpyAsync(occ, d_occ, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        TRY(hipMalloc((void**)&d_tri, (size_t)n * 4));
+        TRY(hipMalloc((void**)&d_t, (size_t)n * 4));
+        if (uv) TRY(hipMalloc((void**)&d_uv, (size_t)n * 8));
+        hipLaunchKernelGGL(k_trace<false>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, d_rays, nullptr, n, d_tri, d_t, d_uv, nullptr, c->d_ctl);
+        TRY(hipGetLastError());
+        if (tri) TRY(hipMemcpyAsync(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (t) TRY(hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (uv) TRY(hipMemcpyAsync(uv, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    TRY(hipStreamSynchronize(c->stream));
+#undef TRY
+    cleanup();
+    return rc;
+}
+
+int pt_trace_closest(pt_ctx* c, const float* o_d, int32_t n, int32_t* tri, float* t, float* uv) {
+    return traceCommon(c, false, o_d, nullptr, n, tri, t, uv, nullptr);
+}
+
+int pt_trace_occluded(pt_ctx* c, const float* o_d, const float* tmax, int32_t n, uint8_t* occluded) {
+    if (n > 0 && (!tmax || !occluded)) return PT_E_INVALID_ARG;
+    return traceCommon(c, true, o_d, tmax, n, nullptr, nullptr, nullptr, occluded);
+}
+
+int pt_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, float* o_d, uint32_t* pixel) {
+    if (!c || !frame_state112 || !o_d || !pixel || n < 0) return PT_E_INVALID_ARG;
+    if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_generate_rays before pt_resize");
+    if (!c->has_rs) FAIL(c, PT_E_STATE, "pt_generate_rays before pt_set_render_state");
+    if ((uint32_t)n > c->slots) FAIL(c, PT_E_INVALID_ARG, "pt_generate_rays: n %d > local slots %u", n, c->slots);
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    HostFrameState fs;
+    memcpy(&fs, frame_state112, sizeof(fs));
+    int rc = renderBatches(c, fs, 1, 1, true);
+    if (rc != PT_OK) return rc;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    Ctl ctl;
+    HIPCHECK(c, hipMemcpy(&ctl, c->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    const uint32_t cnt = ctl.count[0];
+    std::vector<float4> o(cnt), d(cnt);
+    HIPCHECK(c, hipMemcpy(o.data(), c->q.o[0], (size_t)cnt * 16, hipMemcpyDeviceToHost));
+    HIPCHECK(c, hipMemcpy(d.data(), c->q.d[0], (size_t)cnt * 16, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) { pixel[i] = 0xFFFFFFFFu; for (int k = 0; k < 6; k++) o_d[6 * i + k] = 0.0f; }
+    const uint32_t gcx = (uint32_t)(c->width + 7) / 8;
+    auto compact = [](uint32_t x) { x &= 0x55555555; x = (x ^ (x >> 1)) & 0x33333333; x = (x ^ (x >> 2)) & 0x0f0f0f0f; x = (x ^ (x >> 4)) & 0x00ff00ff; x = (x ^ (x >> 8)) & 0x0000ffff; return x; };
+    for (uint32_t j = 0; j < cnt; j++) {
+        uint32_t birth;
+        memcpy(&birth, &o[j].w, 4);
+        if (birth >= (uint32_t)n) continue;
+        const uint32_t group = (birth >> 6) * (uint32_t)c->cfg.tile_world + (uint32_t)c->cfg.tile_rank, lid = birth & 63u;
+        const uint32_t sx = (group % gcx) * 8 + compact(lid), sy = (group / gcx) * 8 + compact(lid >> 1);
+        pixel[birth] = sx + sy * (uint32_t)c->width;
+        o_d[6 * birth] = o[j].x; o_d[6 * birth + 1] = o[j].y; o_d[6 * birth + 2] = o[j].z;
+        o_d[6 * birth + 3] = d[j].x; o_d[6 * birth + 4] = d[j].y; o_d[6 * birth + 5] = d[j].z;
+    }
+    // the debug batch must not count as rendered samples
+    HIPCHECK(c, hipMemset(c->d_ctl, 0, offsetof(Ctl, paths)));
+    return PT_OK;
+}
+
+int pt_get_stats(pt_ctx* c, pt_stats* out) {
+    if (!c || !out) return PT_E_INVALID_ARG;
+    int rc = pt_synchronize(c);
+    if (rc != PT_OK) return rc;
+    Ctl ctl;
+    HIPCHECK(c, hipMemcpy(&ctl, c->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    pt_stats s = c->host_stats;
+    s.paths = ctl.paths;
+    s.extend_rays = ctl.extend_rays;
+    s.shadow_rays = ctl.shadow_rays;
+    s.extend_steps = ctl.extend_steps;
+    s.extend_tris = ctl.extend_tris;
+    s.shadow_steps = ctl.shadow_steps;
+    s.shadow_tris = ctl.shadow_tris;
+    s.stack_overflows = ctl.stack_overflows;
+    *out = s;
+    return PT_OK;
+}
+
+int pt_reset_stats(pt_ctx* c) {
+    if (!c) return PT_E_INVALID_ARG;
+    int rc = pt_synchronize(c);
+    if (rc != PT_OK) return rc;
+    HIPCHECK(c, hipMemset(c->d_ctl, 0, sizeof(Ctl)));
+    c->host_stats = pt_stats{};
+    return PT_OK;
+}
+
+}  // extern "C"

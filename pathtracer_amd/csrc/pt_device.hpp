@@ -1,0 +1,320 @@
+// Device-side building blocks of the wavefront path tracer (gfx950, wave64).
+//
+// Numerics contract: this file is compiled with -ffp-contract=off and without
+// fast-math, and uses only IEEE +,-,*,/,sqrt,floor and comparisons, so every
+// value is reproducible bit for bit on a CPU.  Division and sqrt are the
+// correctly rounded forms (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_WAVE 64
+#define PT_STACK_LDS 16      // traversal stack entries kept in LDS per lane
+#define PT_STACK_SPILL 48    // further entries in per-lane scratch
+#define PT_STACK_TOTAL (PT_STACK_LDS + PT_STACK_SPILL)
+#define PT_EPSILON 0.00001f  // extend.glsl:4 / shade.glsl:4
+#define PT_PI 3.14159274101257324f
+#define PT_INVPI 0.318309873342514038f
+#define PT_INF __builtin_huge_valf()
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+// System.Numerics.Vector3.Dot order: (x*x' + y*y') + z*z'   (Triangle.cs:21-40 call sites)
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ f3 normalize3(f3 a) { float l = sqrtf(dot3(a, a)); return mk3(a.x / l, a.y / l, a.z / l); }
+__device__ __forceinline__ f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+
+struct f4 { float x, y, z, w; };
+__device__ __forceinline__ f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+__device__ __forceinline__ f4 from4(float4 v) { return mk4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 to4(f4 v) { return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ f4 operator*(f4 a, f4 b) { return mk4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ f4 operator*(f4 a, float s) { return mk4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ f4 operator/(f4 a, float s) { return mk4(a.x / s, a.y / s, a.z / s, a.w / s); }
+__device__ __forceinline__ f4 operator+(f4 a, f4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ------------------------------------------------------------ scene on device
+// pairs:    one 64-byte record per sibling pair = the host's Node[2k+1], Node[2k+2] verbatim
+//           (Node.cs:5-10), 64-byte aligned so one traversal step is one cache line.
+// tri_hot:  48 B per triangle: (V1.xyz, material bits) (V2-V1, 0) (V3-V1, 0) — all the hit test reads.
+// tri_cold: 48 B per triangle: the three vertex normals, read once per shaded hit.
+// mats:     the host's Material[] verbatim (48 B = 3 x float4).
+// lights:   48 B per emissive triangle: (V1, running area sum) (V2, material bits) (V3, 0).
+struct DevScene {
+    const float4* pairs;
+    const float4* tri_hot;
+    const float4* tri_cold;
+    const float4* mats;
+    const float4* lights;
+    int32_t n_nodes, n_tris, n_lights;
+    float light_total;
+    float root_min[3], root_max[3];
+    int32_t root_left, root_count;
+};
+
+// Counters and queue sizes shared by the stages of one context (device memory).
+struct Ctl {
+    uint32_t count[2];        // live rays in the ping/pong path queues
+    uint32_t shadow_count;    // rays in the shadow queue
+    uint32_t cursor_extend;   // next unclaimed ray of the running extend launch
+    uint32_t cursor_connect;
+    uint32_t pad[3];
+    unsigned long long paths, extend_rays, shadow_rays, extend_steps, extend_tris, shadow_steps, shadow_tris, stack_overflows;
+};
+
+// ------------------------------------------------ deterministic elementary fns
+// Fixed polynomials (Cephes single-precision coefficients, three-constant
+// Cody-Waite reduction); arguments here are in [0, 2*pi] for sin/cos.
+__device__ __forceinline__ void det_sincos(float x, float* s, float* c) {
+    float k = floorf(x * 0.636619772f + 0.5f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    float z = r * r;
+    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    int q = ((int)k) & 3;
+    float ss = (q & 1) ? cp : sp;
+    float cc = (q & 1) ? sp : cp;
+    if (q == 1 || q == 2) cc = -cc;
+    if (q >= 2) ss = -ss;
+    *s = ss;
+    *c = cc;
+}
+
+__device__ __forceinline__ float det_exp(float x) {
+    if (x > 88.0f) return PT_INF;
+    if (x < -87.0f) return 0.0f;
+    float n = floorf(x * 1.44269504088896341f + 0.5f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    float z = r * r;
+    float p = ((((1.9875691500e-4f * r + 1.3981999507e-3f) * r + 8.3334519073e-3f) * r + 4.1665795894e-2f) * r + 1.6666665459e-1f) * r + 5.0000001201e-1f;
+    float y = p * z + r + 1.0f;
+    return y * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
+
+__device__ __forceinline__ float pow5(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x; }
+__device__ __forceinline__ float clamp01(float x) { float a = (x < 0.0f) ? 0.0f : x; return (1.0f < a) ? 1.0f : a; }
+__device__ __forceinline__ float max0(float x) { return (0.0f < x) ? x : 0.0f; }
+
+// ------------------------------------------------------------------ random
+// generate.glsl:10-21
+__device__ __forceinline__ void xorShift(uint32_t& seed) {
+    seed ^= seed << 13;
+    seed ^= seed >> 17;
+    seed ^= seed << 5;
+}
+__device__ __forceinline__ float randomFloat(uint32_t& seed) {
+    xorShift(seed);
+    return (float)seed * 2.3283064365386963e-10f;   // float(1.0 / 4294967295.0) is 2^-32
+}
+__device__ __forceinline__ uint32_t pcg(uint32_t v) {
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+#define PT_STREAM_GENERATE 2983742873u   // generate.glsl:174
+#define PT_STREAM_SHADE 984524691u       // shade.glsl:352
+#define PT_STREAM_NEE 0x68E31DA4u
+// One stream per (path, frame, stage, bounce).  Mode 0 is the reference's formula with the
+// bounce mixed in; mode 1 hashes so that frame 0 and thread 0 are not degenerate.
+__device__ __forceinline__ uint32_t streamSeed(uint32_t gidx, uint32_t frames, uint32_t stream, uint32_t bounce, int mode) {
+    uint32_t seed;
+    if (mode == 0) {
+        seed = gidx * 57028723u * frames * 87029659u + stream + bounce * 0x9E3779B9u;
+    } else {
+        seed = pcg(pcg(gidx + pcg(frames)) + stream + bounce * 0x9E3779B9u);
+        if (seed == 0) seed = 1;
+    }
+    xorShift(seed); xorShift(seed); xorShift(seed);
+    return seed;
+}
+
+// generate.glsl:160-168
+__device__ __forceinline__ uint32_t compactBits(uint32_t x) {
+    x &= 0x55555555;
+    x = (x ^ (x >> 1)) & 0x33333333;
+    x = (x ^ (x >> 2)) & 0x0f0f0f0f;
+    x = (x ^ (x >> 4)) & 0x00ff00ff;
+    x = (x ^ (x >> 8)) & 0x0000ffff;
+    return x;
+}
+
+// Local slot -> pixel.  64 consecutive slots are one 8x8 Morton tile (generate.glsl:177-187);
+// global tile g belongs to rank g % world as that rank's local tile g / world.  gidx is the
+// thread index a single-GPU run gives the same pixel; it keys the random streams, which
+// makes the image independent of the number of GPUs.
+__device__ __forceinline__ bool pixelOfSlot(uint32_t slot, int width, int height, int rank, int world, uint32_t* pixel, uint32_t* gidx) {
+    uint32_t gcx = (uint32_t)(width + 7) / 8, gcy = (uint32_t)(height + 7) / 8;
+    uint32_t lid = slot & 63u;
+    uint32_t group = (slot >> 6) * (uint32_t)world + (uint32_t)rank;
+    if (group >= gcx * gcy) return false;
+    uint32_t gx = group % gcx, gy = group / gcx;
+    uint32_t sx = gx * 8 + compactBits(lid), sy = gy * 8 + compactBits(lid >> 1);
+    if (sx >= (uint32_t)width || sy >= (uint32_t)height) return false;
+    *pixel = sx + sy * (uint32_t)width;
+    *gidx = group * 64u + lid;
+    return true;
+}
+
+// --------------------------------------------------------------- wave helpers
+__device__ __forceinline__ uint32_t laneId() { return __lane_id(); }
+
+// Dense output slot for every lane with alive == true: ballot + prefix popcount, one
+// atomic per wave.  Lanes with alive == false get an unspecified value.
+__device__ __forceinline__ uint32_t waveAppend(bool alive, uint32_t* counter) {
+    unsigned long long mask = __ballot(alive);
+    if (mask == 0ull) return 0;
+    uint32_t lane = laneId();
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ void waveAdd64(unsigned long long* counter, uint32_t v) {
+    // sum over the active lanes, one atomic per wave
+    unsigned long long total = v;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if (laneId() == 0) atomicAdd(counter, total);
+}
+
+// ------------------------------------------------------------------ traversal
+struct HitRec { float t; int32_t tri; float u, v; };
+
+// Box.cs:51-79.  The host's MathF.Min/Max propagate NaN, which makes a box test with a
+// NaN slab distance a miss; v_min/v_max drop NaN, so the NANSAFE form rejects it
+// explicitly.  A NaN can only come from 0 * inf, i.e. a ray with a zero (or denormal)
+// direction component, so rays without one take the cheaper form with identical results.
+template <bool NANSAFE>
+__device__ __forceinline__ bool slabTest(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, f3 o, f3 inv, float* tmin) {
+    float t1 = (mnx - o.x) * inv.x;
+    float t2 = (mxx - o.x) * inv.x;
+    float t3 = (mny - o.y) * inv.y;
+    float t4 = (mxy - o.y) * inv.y;
+    float t5 = (mnz - o.z) * inv.z;
+    float t6 = (mxz - o.z) * inv.z;
+    float tmn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    float tmx = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    bool hit = tmx > 0.0f && tmn < tmx;
+    if (NANSAFE) hit = hit && !((t1 != t1) | (t2 != t2) | (t3 != t3) | (t4 != t4) | (t5 != t5) | (t6 != t6));
+    *tmin = tmn;
+    return hit;
+}
+
+// Triangle.cs:15-47 with edge1 = V2-V1 and edge2 = V3-V1 taken from the hot record (the
+// same two subtractions, done once at upload).  Returns dist > 0 acceptance; the caller
+// compares against its current best.
+__device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float* dist, float* u_out, float* v_out) {
+    f3 v1 = xyz(q0), edge1 = xyz(q1), edge2 = xyz(q2);
+    f3 h = cross3(d, edge2);
+    float a = dot3(edge1, h);
+    float f = 1.0f / a;
+    f3 s = o - v1;
+    float u = f * dot3(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 q = cross3(s, edge1);
+    float v = f * dot3(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = f * dot3(edge2, q);
+    *dist = t;
+    *u_out = u;
+    *v_out = v;
+    return t > 0.0f;
+}
+
+// Closest hit (ANYHIT = false) or any hit closer than tlimit (ANYHIT = true) for one ray per lane.
+//
+// One step = one 64-byte sibling-pair fetch.  Both children are slab-tested; a child is
+// skipped when its entry distance lies beyond the best hit (closest: tmin > best, so a
+// child entered exactly at the best distance is still visited and an equal-distance
+// triangle with a smaller index can win; any-hit: tmin >= tlimit).  Hit leaf children
+// are tested at once, left then right; of two hit interior children the nearer is
+// visited next and the other pushed.  Closest-hit ties go to the smaller triangle index.
+// The stack holds node indices of left children: PT_STACK_LDS entries per lane in LDS
+// (lstack[e * 64 + lane], conflict free), the rest in scratch.
+template <bool NANSAFE, bool ANYHIT, bool STATS>
+__device__ __forceinline__ bool traverseScene(const DevScene& sc, f3 o, f3 d, float tlimit, HitRec* hit, uint32_t* lstack,
+                                              uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow) {
+    float best = tlimit;
+    int32_t bestTri = -1;
+    float bu = 0.0f, bv = 0.0f;
+    bool occluded = false;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // Ray.cs:18
+    const uint32_t lane = laneId();
+    uint32_t spill[PT_STACK_SPILL];
+
+    auto testLeaf = [&](int32_t first, int32_t count) {
+        for (int32_t j = first; j < first + count; j++) {
+            const float4* p = sc.tri_hot + 3 * (size_t)j;
+            float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            if (STATS) (*ntris)++;
+            float t, u, v;
+            if (triangleTest(q0, q1, q2, o, d, &t, &u, &v)) {
+                if (ANYHIT) {
+                    if (t < tlimit) { occluded = true; return; }
+                } else if (t < best || (t == best && j < bestTri)) {
+                    best = t; bestTri = j; bu = u; bv = v;
+                }
+            }
+        }
+    };
+
+    bool alive = sc.n_nodes > 0;
+    if (alive) {
+        float tr;
+        // the root test is done once per ray: always the NaN-propagating form
+        alive = slabTest<true>(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], o, inv, &tr);
+    }
+    if (alive && sc.root_count > 0) {
+        testLeaf(sc.root_left, sc.root_count);
+        alive = false;
+    }
+    int32_t cur = sc.root_left;
+    int sp = 0;
+    while (alive) {
+        if (STATS) (*nsteps)++;
+        const float4* p = sc.pairs + 2 * (size_t)(cur - 1);   // pair (cur-1)/2, 4 float4 each
+        const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+        float lt, rt;
+        bool lhit = slabTest<NANSAFE>(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, &lt);
+        bool rhit = slabTest<NANSAFE>(c.x, c.y, c.z, c.w, e.x, e.y, o, inv, &rt);
+        if (ANYHIT) { lhit = lhit && lt < tlimit; rhit = rhit && rt < tlimit; }
+        else { lhit = lhit && !(lt > best); rhit = rhit && !(rt > best); }
+        const int32_t lfirst = __float_as_int(b.z), lcount = __float_as_int(b.w);
+        const int32_t rfirst = __float_as_int(e.z), rcount = __float_as_int(e.w);
+        if (lhit && lcount > 0) { testLeaf(lfirst, lcount); lhit = false; }
+        if (ANYHIT && occluded) break;
+        if (rhit && rcount > 0) { testLeaf(rfirst, rcount); rhit = false; }
+        if (ANYHIT && occluded) break;
+        if (lhit && rhit) {
+            int32_t farChild, nearChild;
+            if (rt < lt) { nearChild = rfirst; farChild = lfirst; }
+            else { nearChild = lfirst; farChild = rfirst; }
+            if (sp < PT_STACK_LDS) lstack[sp * PT_WAVE + lane] = (uint32_t)farChild;
+            else if (sp < PT_STACK_TOTAL) spill[sp - PT_STACK_LDS] = (uint32_t)farChild;
+            else { (*overflow)++; sp--; }   // drop the far subtree; counted, never silent
+            sp++;
+            cur = nearChild;
+        } else if (lhit) {
+            cur = lfirst;
+        } else if (rhit) {
+            cur = rfirst;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            cur = (int32_t)((sp < PT_STACK_LDS) ? lstack[sp * PT_WAVE + lane] : spill[sp - PT_STACK_LDS]);
+        }
+    }
+    if (!ANYHIT) { hit->t = best; hit->tri = bestTri; hit->u = bu; hit->v = bv; }
+    return occluded;
+}

@@ -1,0 +1,462 @@
+// The wavefront stages as HIP kernels: generate -> { extend -> shade -> connect } x bounces -> resolve.
+// Ray queues are arrays of 16-byte columns in HBM (origin+birth, direction+flags, throughput, hit),
+// so every queue access is one coalesced dwordx4 per lane.
+#pragma once
+#include "pt_device.hpp"
+
+#define PT_BLOCK 256
+
+// A slab distance can be NaN only for a ray with a zero/denormal/non-finite direction
+// component or a non-finite origin; such rays take the NaN-rejecting traversal.
+__device__ __forceinline__ bool raySpecial(f3 o, f3 d) {
+    const bool dOk = fabsf(d.x) >= 1.0e-37f && fabsf(d.x) <= 3.0e38f && fabsf(d.y) >= 1.0e-37f && fabsf(d.y) <= 3.0e38f &&
+                     fabsf(d.z) >= 1.0e-37f && fabsf(d.z) <= 3.0e38f;
+    const bool oOk = fabsf(o.x) <= 3.0e38f && fabsf(o.y) <= 3.0e38f && fabsf(o.z) <= 3.0e38f;
+    return !(dOk && oOk);
+}
+
+struct RenderParams {
+    int32_t width, height;
+    float sky[4];
+    // FrameState.Camera (State.cs:9-18)
+    float p1[3], p2[3], p3[3], pos[3], right[3], up[3];
+    uint32_t frames0;          // FrameState.Frames of the batch's first sample
+    uint32_t slots;            // local pixel slots (local groups * 64)
+    uint32_t samples;          // samples in this batch
+    int32_t rank, world;
+    int32_t rng_mode, nee;
+    int32_t bounce, last_bounce;
+};
+
+struct Queues {
+    float4* o[2];      // origin.xyz, birth index (bits)
+    float4* d[2];      // direction.xyz, flags (bits): bit0 = previous vertex was specular
+    float4* T[2];      // throughput rgba
+    float4* hit;       // t, triangle (bits), u, v
+    float4* so;        // shadow origin.xyz, tmax
+    float4* sd;        // shadow direction.xyz, birth (bits)
+    float4* sc;        // shadow contribution rgba
+    float4* plane;     // per-path radiance of the batch, indexed by birth
+};
+
+// ------------------------------------------------------------------ generate
+// generate.glsl:135-156, 170-200.  Thread k of the batch: sample k / slots, local slot k % slots.
+__global__ void __launch_bounds__(PT_BLOCK) k_generate(RenderParams rp, Queues q, Ctl* ctl) {
+    const uint32_t total = rp.slots * rp.samples;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = k < total;
+    uint32_t pixel = 0, gidx = 0;
+    uint32_t sample = 0, slot = 0;
+    if (valid) {
+        sample = k / rp.slots;
+        slot = k - sample * rp.slots;
+        valid = pixelOfSlot(slot, rp.width, rp.height, rp.rank, rp.world, &pixel, &gidx);
+    }
+    f3 origin = mk3(0, 0, 0), dir = mk3(0, 0, 0);
+    if (valid) {
+        uint32_t seed = streamSeed(gidx, rp.frames0 + sample, PT_STREAM_GENERATE, 0, rp.rng_mode);
+        const uint32_t sx = pixel % (uint32_t)rp.width, sy = pixel / (uint32_t)rp.width;
+        const float r0 = randomFloat(seed);
+        const float r1 = randomFloat(seed);
+        const float r2 = randomFloat(seed) - 0.5f;
+        const float r3 = randomFloat(seed) - 0.5f;
+        const float x = ((float)sx + r0) / (float)rp.width;
+        const float y = ((float)((uint32_t)rp.height - sy) + r1) / (float)rp.height;
+        const f3 P1 = mk3(rp.p1[0], rp.p1[1], rp.p1[2]), P2 = mk3(rp.p2[0], rp.p2[1], rp.p2[2]), P3 = mk3(rp.p3[0], rp.p3[1], rp.p3[2]);
+        const f3 pos = mk3(rp.pos[0], rp.pos[1], rp.pos[2]), right = mk3(rp.right[0], rp.right[1], rp.right[2]), up = mk3(rp.up[0], rp.up[1], rp.up[2]);
+        const f3 t = (P1 + x * (P2 - P1)) + y * (P3 - P1);
+        const f3 p = pos + 0.05f * (r2 * right + r3 * up);
+        dir = normalize3(t - p);
+        origin = p;
+    }
+    const uint32_t out = waveAppend(valid, &ctl->count[0]);
+    if (valid) {
+        q.o[0][out] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(k));
+        q.d[0][out] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(1u));
+        q.T[0][out] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);   // generate.glsl:199
+    }
+}
+
+// -------------------------------------------------------------------- extend
+// extend.glsl:301-309.  Persistent waves claim 64 rays at a time from a shared cursor, so
+// cheap (sky) and expensive rays balance across the chip without a host round trip.
+template <bool STATS>
+__global__ void __launch_bounds__(PT_BLOCK) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur) {
+    __shared__ uint32_t lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
+    uint32_t* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
+    const uint32_t n = ctl->count[cur];
+    const uint32_t lane = laneId();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // counters of the stages that follow this launch
+        ctl->count[cur ^ 1] = 0;
+        ctl->shadow_count = 0;
+        atomicAdd(&ctl->extend_rays, (unsigned long long)n);
+    }
+    uint32_t steps = 0, tris = 0, overflow = 0;
+    while (true) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctl->cursor_extend, PT_WAVE);
+        base = __shfl(base, 0);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const float4 ro = q.o[cur][i], rd = q.d[cur][i];
+            const f3 o = xyz(ro), d = xyz(rd);
+            HitRec h;
+            const bool special = raySpecial(o, d);
+            if (__any(special)) traverseScene<true, false, STATS>(sc, o, d, PT_INF, &h, lstack, &steps, &tris, &overflow);
+            else traverseScene<false, false, STATS>(sc, o, d, PT_INF, &h, lstack, &steps, &tris, &overflow);
+            q.hit[i] = make_float4(h.t, __int_as_float(h.tri), h.u, h.v);
+        }
+    }
+    if (STATS) {
+        waveAdd64(&ctl->extend_steps, steps);
+        waveAdd64(&ctl->extend_tris, tris);
+    }
+    if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
+}
+
+// ------------------------------------------------------------------- connect
+// Shadow rays of next-event estimation (no reference counterpart).  Unoccluded rays add
+// their contribution to the path's radiance.
+template <bool STATS>
+__global__ void __launch_bounds__(PT_BLOCK) k_connect(DevScene sc, Queues q, Ctl* ctl) {
+    __shared__ uint32_t lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
+    uint32_t* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
+    const uint32_t n = ctl->shadow_count;
+    const uint32_t lane = laneId();
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->shadow_rays, (unsigned long long)n);
+    uint32_t steps = 0, tris = 0, overflow = 0;
+    while (true) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctl->cursor_connect, PT_WAVE);
+        base = __shfl(base, 0);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const float4 ro = q.so[i], rd = q.sd[i];
+            const f3 o = xyz(ro), d = xyz(rd);
+            const bool special = raySpecial(o, d);
+            bool occ;
+            if (__any(special)) occ = traverseScene<true, true, STATS>(sc, o, d, ro.w, nullptr, lstack, &steps, &tris, &overflow);
+            else occ = traverseScene<false, true, STATS>(sc, o, d, ro.w, nullptr, lstack, &steps, &tris, &overflow);
+            if (!occ) {
+                const uint32_t birth = __float_as_uint(rd.w);
+                const f4 c = from4(q.sc[i]);
+                q.plane[birth] = to4(from4(q.plane[birth]) + c);
+            }
+        }
+    }
+    if (STATS) {
+        waveAdd64(&ctl->shadow_steps, steps);
+        waveAdd64(&ctl->shadow_tris, tris);
+    }
+    if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
+}
+
+// --------------------------------------------------------------------- shade
+// shade.glsl:150-162
+__device__ __forceinline__ float schlick(f3 direction, f3 normal, float n1, float n2) {
+    float r0 = (n1 - n2) / (n1 + n2);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * pow5(1.0f - dot3(normal, neg3(direction)));
+}
+__device__ __forceinline__ f3 schlick3(f3 ks, f3 l, f3 n) {
+    const float ldotn = clamp01(dot3(l, n));
+    const float p = pow5(1.0f - ldotn);
+    return mk3(ks.x + (1.0f - ks.x) * p, ks.y + (1.0f - ks.y) * p, ks.z + (1.0f - ks.z) * p);
+}
+// shade.glsl:164-194
+__device__ __forceinline__ float smithGgxMasking(f3 v, f3 n, float a2) {
+    const float ndotv = clamp01(dot3(n, v));
+    const float c = sqrtf(a2 + (1.0f - a2) * ndotv * ndotv) + ndotv;
+    if (c == 0.0f) return 0.0f;
+    return 2.0f * ndotv / c;
+}
+__device__ __forceinline__ float smithGgxShadowMasking(f3 l, f3 v, f3 n, float a2) {
+    const float ndotl = clamp01(dot3(n, l));
+    const float ndotv = clamp01(dot3(n, v));
+    const float a = ndotv * sqrtf(a2 + (1.0f - a2) * ndotl * ndotl);
+    const float b = ndotl * sqrtf(a2 + (1.0f - a2) * ndotv * ndotv);
+    const float denom = a + b;
+    if (denom == 0.0f) return 0.0f;
+    return 2.0f * ndotl * ndotv / denom;
+}
+__device__ __forceinline__ f3 reflect3(f3 i, f3 n) { float d2 = 2.0f * dot3(n, i); return i - d2 * n; }
+
+// shade.glsl:210-225
+__device__ __forceinline__ f3 lambertImportanceSample(f3 normal, uint32_t& seed) {
+    const f3 axis = fabsf(normal.x) > 0.95f ? mk3(0, 1, 0) : mk3(1, 0, 0);
+    const f3 u = normalize3(cross3(normal, axis));
+    const f3 v = cross3(u, normal);
+    const float r0 = randomFloat(seed);
+    const float r1 = randomFloat(seed);
+    const float r = sqrtf(r0);
+    const float theta = 2.0f * PT_PI * r1;
+    float st, ct;
+    det_sincos(theta, &st, &ct);
+    return ((r * ct) * u + (r * st) * v) + sqrtf(1.0f - r0) * normal;
+}
+
+// shade.glsl:238-257
+__device__ __forceinline__ f3 ggxImportance(f3 view, float alpha, uint32_t& seed) {
+    const float r1 = randomFloat(seed);
+    const float r2 = randomFloat(seed);
+    const f3 wo = normalize3(mk3(view.x * alpha, view.y * alpha, view.z));
+    const f3 t1 = (wo.z < 0.999f) ? normalize3(cross3(wo, mk3(0, 0, 1))) : mk3(1, 0, 0);
+    const f3 t2 = cross3(t1, wo);
+    float a = 1.0f / (1.0f + wo.z);
+    float r = sqrtf(r1);
+    float phi = (r2 < a) ? (r2 / a) * PT_PI : PT_PI + (r2 - a) / (1.0f - a) * PT_PI;
+    float sphi, cphi;
+    det_sincos(phi, &sphi, &cphi);
+    float p1 = r * cphi;
+    float p2 = r * sphi * ((r2 < a) ? 1.0f : wo.z);
+    f3 n = (p1 * t1 + p2 * t2) + sqrtf(max0(1.0f - p1 * p1 - p2 * p2)) * wo;
+    return normalize3(mk3(alpha * n.x, alpha * n.y, max0(n.z)));
+}
+
+// shade.glsl:296-330
+__device__ __forceinline__ f4 sampleGgx(f3 color, float roughness, f3 world_n, f3 world_v, f3* world_l, uint32_t& seed) {
+    f3 W = fabsf(world_n.x) > 0.9f ? mk3(0, 1, 0) : mk3(1, 0, 0);
+    f3 N = world_n;
+    f3 T = normalize3(cross3(N, W));
+    f3 B = cross3(N, T);
+    f3 v = mk3(dot3(world_v, T), dot3(world_v, B), dot3(world_v, N));
+    f3 m = ggxImportance(v, roughness, seed);
+    f3 l = reflect3(neg3(v), m);
+    if (dot3(l, m) < 0.0f) return mk4(0, 0, 0, 0);
+    *world_l = (l.x * T + l.y * B) + l.z * N;
+    float a2 = roughness * roughness;
+    f3 f = schlick3(color, m, l);
+    float g1 = smithGgxMasking(v, m, a2);
+    float g2 = smithGgxShadowMasking(l, v, m, a2);
+    if (g1 == 0.0f) return mk4(0, 0, 0, 0);
+    float g = g2 / g1;
+    return mk4(f.x * g, f.y * g, f.z * g, 0.0f * g);
+}
+
+// smallest i with r * total < running_sum[i] (area-proportional light choice)
+__device__ __forceinline__ int pickLight(const DevScene& sc, float r) {
+    const float target = r * sc.light_total;
+    int lo = 0, hi = sc.n_lights - 1;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (target < sc.lights[3 * mid].w) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// shade.glsl:349-459 plus next-event estimation.  Terminated paths add their radiance to
+// plane[birth] (one live path per birth index, so a plain read-modify-write is race free);
+// survivors are appended to the other queue by wave-level ballot/prefix compaction.
+__global__ void __launch_bounds__(PT_BLOCK) k_shade(DevScene sc, RenderParams rp, Queues q, Ctl* ctl, int cur) {
+    const uint32_t n = ctl->count[cur];
+    const int nxt = cur ^ 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->cursor_extend = 0;
+        ctl->cursor_connect = 0;
+    }
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // every lane of a wave runs the same number of iterations: the compaction below is wave-wide
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t it = 0; it < rounds; it++) {
+        const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool active = i < n;
+        bool survive = false, shadow = false;
+        f3 newO = mk3(0, 0, 0), newD = mk3(0, 0, 0);
+        f4 newT = mk4(0, 0, 0, 0);
+        uint32_t newFlags = 0, birth = 0;
+        f3 sO = mk3(0, 0, 0), sD = mk3(0, 0, 0);
+        float sTmax = 0.0f;
+        f4 sC = mk4(0, 0, 0, 0);
+        if (active) {
+            const float4 ro = q.o[cur][i], rd = q.d[cur][i];
+            const f3 o = xyz(ro), d = xyz(rd);
+            birth = __float_as_uint(ro.w);
+            const bool lastSpecular = (__float_as_uint(rd.w) & 1u) != 0u;
+            const f4 T = from4(q.T[cur][i]);
+            const float4 hr = q.hit[i];
+            const int32_t tri = __float_as_int(hr.y);
+            const uint32_t sample = birth / rp.slots;
+            const uint32_t slot = birth - sample * rp.slots;
+            const uint32_t gidx = ((slot >> 6) * (uint32_t)rp.world + (uint32_t)rp.rank) * 64u + (slot & 63u);
+            const uint32_t frames = rp.frames0 + sample;
+            uint32_t seed = streamSeed(gidx, frames, PT_STREAM_SHADE, (uint32_t)rp.bounce, rp.rng_mode);
+            f4 add = mk4(0, 0, 0, 0);
+            bool addIt = false;
+            if (tri < 0) {
+                add = T * mk4(rp.sky[0], rp.sky[1], rp.sky[2], rp.sky[3]);   // shade.glsl:358-362
+                addIt = true;
+            } else {
+                const float4 h0 = sc.tri_hot[3 * (size_t)tri];
+                const int32_t matId = __float_as_int(h0.w);
+                const float4 m0 = sc.mats[3 * matId], m1 = sc.mats[3 * matId + 1], m2 = sc.mats[3 * matId + 2];
+                const f4 color = from4(m0);
+                const int32_t type = __float_as_int(m2.x);
+                const float index = m2.y, roughness = m2.z;
+                if (m1.x > 0.0f || m1.y > 0.0f || m1.z > 0.0f) {   // shade.glsl:366-370
+                    if (!rp.nee || lastSpecular) { add = T * from4(m1); addIt = true; }
+                } else {
+                    const float4 c0 = sc.tri_cold[3 * (size_t)tri], c1 = sc.tri_cold[3 * (size_t)tri + 1], c2 = sc.tri_cold[3 * (size_t)tri + 2];
+                    const float hu = hr.z, hv = hr.w;
+                    const float w = 1.0f - hu - hv;
+                    f3 normal = normalize3((xyz(c0) * w + xyz(c1) * hu) + xyz(c2) * hv);
+                    const float dist = hr.x;
+                    f3 bounce = mk3(0, 0, 0);
+                    f4 throughput = T;
+                    const f3 hitP = o + d * dist;
+                    bool dead = false;
+                    if (type == 2) {   // dielectric, shade.glsl:375-405
+                        float n1 = 1.0f, n2 = index;
+                        if (dot3(d, normal) > 0.0f) {
+                            n1 = index;
+                            n2 = 1.0f;
+                            normal = normal * -1.0f;
+                            throughput.x = throughput.x * det_exp(-color.x * dist);
+                            throughput.y = throughput.y * det_exp(-color.y * dist);
+                            throughput.z = throughput.z * det_exp(-color.z * dist);
+                        }
+                        const float r = randomFloat(seed);
+                        const float sch = schlick(d, normal, n1, n2);
+                        if (r < sch) {
+                            bounce = reflect3(d, normal);
+                        } else {
+                            const float eta = n1 / n2;
+                            const float dn = dot3(normal, d);
+                            const float kk = 1.0f - eta * eta * (1.0f - dn * dn);
+                            if (kk < 0.0f) bounce = reflect3(d, normal);   // total internal reflection
+                            else bounce = eta * d - (eta * dn + sqrtf(kk)) * normal;
+                        }
+                        throughput = throughput * color;
+                    }
+                    if (type == 1) {   // mirror, shade.glsl:407-411
+                        bounce = reflect3(d, normal);
+                        throughput = throughput * color;
+                    }
+                    if (type == 0) {   // diffuse, shade.glsl:413-426
+                        bounce = lambertImportanceSample(normal, seed);
+                        const f4 brdf = color * PT_INVPI;
+                        const float pdf = clamp01(dot3(normal, bounce)) * PT_INVPI;
+                        if (rp.nee && sc.n_lights > 0) {
+                            uint32_t ns = streamSeed(gidx, frames, PT_STREAM_NEE, (uint32_t)rp.bounce, rp.rng_mode);
+                            const float rl = randomFloat(ns);
+                            const float ru = randomFloat(ns);
+                            const float rv = randomFloat(ns);
+                            const int li = pickLight(sc, rl);
+                            const float4 l0 = sc.lights[3 * li], l1 = sc.lights[3 * li + 1], l2 = sc.lights[3 * li + 2];
+                            const f3 lv1 = xyz(l0), lv2 = xyz(l1), lv3 = xyz(l2);
+                            const float su = sqrtf(ru);
+                            const float b0 = 1.0f - su;
+                            const float b1 = rv * su;
+                            const float b2 = 1.0f - b0 - b1;
+                            const f3 yp = (lv1 * b0 + lv2 * b1) + lv3 * b2;
+                            const f3 wv = yp - hitP;
+                            const float dist2 = dot3(wv, wv);
+                            const float dl = sqrtf(dist2);
+                            const f3 wn = wv / dl;
+                            const float cosx = dot3(wn, normal);
+                            const f3 ng = cross3(lv2 - lv1, lv3 - lv1);
+                            const float ngl = sqrtf(dot3(ng, ng));
+                            const float cosy = fabsf(dot3(wn, ng)) / ngl;
+                            if (cosx > 0.0f && cosy > 0.0f && dist2 > 0.0f) {
+                                const float geom = cosx * cosy * sc.light_total / dist2;
+                                const int32_t lm = __float_as_int(l1.w);
+                                sC = (T * brdf) * from4(sc.mats[3 * lm + 1]) * geom;
+                                sO = hitP + wn * PT_EPSILON;
+                                sD = wn;
+                                sTmax = dl * 0.999f;
+                                shadow = true;
+                            }
+                        }
+                        if (pdf == 0.0f) dead = true;   // shade.glsl:419-423
+                        else throughput = throughput * brdf * dot3(bounce, normal) / pdf;
+                    }
+                    if (type == 3) {   // metal, shade.glsl:428-431
+                        throughput = throughput * sampleGgx(mk3(color.x, color.y, color.z), roughness, normal, neg3(d), &bounce, seed);
+                    }
+                    if (!dead) {
+                        float roulette = (throughput.x < throughput.y) ? throughput.y : throughput.x;
+                        roulette = (roulette < throughput.z) ? throughput.z : roulette;
+                        if (!(randomFloat(seed) > roulette)) {   // shade.glsl:433-441
+                            newT = throughput * (1.0f / roulette);
+                            newO = hitP + bounce * PT_EPSILON;
+                            newD = bounce;
+                            newFlags = (type != 0) ? 1u : 0u;
+                            survive = !rp.last_bounce;
+                        }
+                    }
+                }
+            }
+            if (addIt) q.plane[birth] = to4(from4(q.plane[birth]) + add);
+        }
+        const uint32_t slotOut = waveAppend(survive, &ctl->count[nxt]);
+        if (survive) {
+            q.o[nxt][slotOut] = make_float4(newO.x, newO.y, newO.z, __uint_as_float(birth));
+            q.d[nxt][slotOut] = make_float4(newD.x, newD.y, newD.z, __uint_as_float(newFlags));
+            q.T[nxt][slotOut] = to4(newT);
+        }
+        const uint32_t sOut = waveAppend(shadow, &ctl->shadow_count);
+        if (shadow) {
+            q.so[sOut] = make_float4(sO.x, sO.y, sO.z, sTmax);
+            q.sd[sOut] = make_float4(sD.x, sD.y, sD.z, __uint_as_float(birth));
+            q.sc[sOut] = to4(sC);
+        }
+    }
+}
+
+// ------------------------------------------------------------------- resolve
+// sum[slot] += plane[s][slot] for the batch's samples in order: the image does not depend
+// on how many samples were traced concurrently.
+__global__ void __launch_bounds__(PT_BLOCK) k_resolve(float4* sum, const float4* plane, uint32_t slots, uint32_t samples) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= slots) return;
+    f4 acc = from4(sum[slot]);
+    for (uint32_t s = 0; s < samples; s++) acc = acc + from4(plane[(size_t)s * slots + slot]);
+    sum[slot] = to4(acc);
+}
+
+// De-interleaves `world` rank-local accumulators (slots_padded float4 each) into a row-major
+// image and divides by the sample count (the read-out of shade.glsl:89-96's running mean).
+__global__ void __launch_bounds__(PT_BLOCK) k_assemble(const float4* gathered, uint32_t slots_padded, int world, int width, int height, float samples, float4* image) {
+    const uint32_t gcx = (uint32_t)(width + 7) / 8, gcy = (uint32_t)(height + 7) / 8;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= gcx * gcy * 64u) return;
+    const uint32_t group = k >> 6, lid = k & 63u;
+    const uint32_t sx = (group % gcx) * 8 + compactBits(lid), sy = (group / gcx) * 8 + compactBits(lid >> 1);
+    if (sx >= (uint32_t)width || sy >= (uint32_t)height) return;
+    const uint32_t rank = group % (uint32_t)world, local = group / (uint32_t)world;
+    const f4 v = from4(gathered[(size_t)rank * slots_padded + local * 64u + lid]);
+    image[sx + sy * (uint32_t)width] = to4(v / samples);
+}
+
+// ------------------------------------------------------- standalone queries
+template <bool ANYHIT>
+__global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, const float* o_d, const float* tmax, int n, int32_t* tri, float* t, float* uv, uint8_t* occluded, Ctl* ctl) {
+    __shared__ uint32_t lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
+    uint32_t* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t steps = 0, tris = 0, overflow = 0;
+    if (i < n) {
+        const f3 o = mk3(o_d[6 * i], o_d[6 * i + 1], o_d[6 * i + 2]), d = mk3(o_d[6 * i + 3], o_d[6 * i + 4], o_d[6 * i + 5]);
+        if (ANYHIT) {
+            occluded[i] = traverseScene<true, true, false>(sc, o, d, tmax[i], nullptr, lstack, &steps, &tris, &overflow) ? 1 : 0;
+        } else {
+            HitRec h;
+            traverseScene<true, false, false>(sc, o, d, PT_INF, &h, lstack, &steps, &tris, &overflow);
+            tri[i] = h.tri;
+            t[i] = h.t;
+            if (uv) { uv[2 * i] = h.u; uv[2 * i + 1] = h.v; }
+        }
+    }
+    if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
+}
+
+__global__ void k_set_ctl(Ctl* ctl, uint32_t count0, unsigned long long paths) {
+    ctl->count[0] = count0;
+    ctl->count[1] = 0;
+    ctl->shadow_count = 0;
+    ctl->cursor_extend = 0;
+    ctl->cursor_connect = 0;
+    ctl->paths += paths;
+}

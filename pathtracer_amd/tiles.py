@@ -1,0 +1,69 @@
+"""Image tiles across the GPUs of one node: one process per GPU, scene replicated, tiles sharded.
+
+Pixel group g (an 8x8 Morton tile, generate.glsl:177-187) is rendered by rank g % world into
+that rank's own accumulator.  Nothing is exchanged while rendering; once per image the
+accumulators are gathered to rank 0 (RCCL over xGMI when the process group's backend is
+"nccl": a direct gather, each rank sends W*H*16/world bytes once) and de-interleaved there by
+pt_assemble_tiles.  torch is used only for the process group and as a view of device memory.
+"""
+import numpy as np
+
+
+def tile_owner(width, height, world):
+    """rank owning each pixel, shape (height, width) — the partition the kernels implement."""
+    gcx = (width + 7) // 8
+    ys, xs = np.mgrid[0:height, 0:width]
+    group = (ys // 8) * gcx + (xs // 8)
+    return (group % world).astype(np.int32)
+
+
+def local_slots(width, height, rank, world):
+    """(own slot count, padded slot count) of a rank; the padded count is equal on every rank."""
+    groups = ((width + 7) // 8) * ((height + 7) // 8)
+    return ((groups + world - 1 - rank) // world) * 64, ((groups + world - 1) // world) * 64
+
+
+class _DevView:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<f4", "data": (ptr, False), "version": 3, "strides": None}
+
+
+def accumulator_tensor(wf):
+    """Zero-copy torch view (n_slots_padded, 4) of a Wavefront's device accumulator."""
+    import torch
+    ptr, n, _ = wf.accum_device()
+    return torch.as_tensor(_DevView(ptr, int(n)), device=torch.device("cuda", torch.cuda.current_device()))
+
+
+def gather_accumulators(local, dst=0, group=None):
+    """Gather every rank's accumulator tensor to `dst`.  Returns (world, n, 4) there, None elsewhere.
+
+    Works on any backend: with "nccl" the tensors stay on the GPU and move over xGMI via RCCL;
+    with "gloo" they are CPU tensors (used by the CPU tests of the multi-rank path).
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return local.unsqueeze(0)
+    if rank == dst:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.gather(local, list(out.unbind(0)), dst=dst, group=group)
+        return out
+    dist.gather(local, None, dst=dst, group=group)
+    return None
+
+
+def gather_image(wf, samples, dst=0, group=None):
+    """Synchronise the context, gather all ranks' tiles and assemble the image on `dst` (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    wf.synchronize()
+    local = accumulator_tensor(wf)
+    gathered = gather_accumulators(local, dst=dst, group=group)
+    if gathered is None:
+        return None
+    torch.cuda.synchronize()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    return wf.assemble_tiles(gathered.data_ptr(), world, samples)
