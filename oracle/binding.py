@@ -176,13 +176,13 @@ class Scene:
         _chk(lib().orc_camera(self.h if use_scene else None, _p(pos), _p(tgt), width, height, _p(fs), C.byref(focal)))
         return fs, focal.value
 
-    def render(self, rs, fs, cfg, spp, traversal="canonical", threads=8, max_groups=0, sum_buffer=None):
+    def render(self, rs, fs, cfg, spp, traversal="canonical", threads=8, max_groups=0, sum_buffer=None, group_stride=1):
         """Adds spp samples into a (H,W,4) sum; returns (sum, stats dict)."""
         w, h = int(rs["width"][0]), int(rs["height"][0])
         s = np.zeros((h, w, 4), np.float32) if sum_buffer is None else sum_buffer
         st = np.zeros(8, np.uint64)
         _chk(lib().orc_render(self.h, _p(rs), _p(fs), _p(cfg), spp, _p(s), _p(st),
-                              {"literal": 0, "canonical": 1}[traversal], threads, max_groups))
+                              {"literal": 0, "canonical": 1}[traversal], threads, max_groups, group_stride))
         names = ["extend_rays", "shadow_rays", "extend_steps", "extend_tris", "shadow_steps", "shadow_tris"]
         return s, {k: int(v) for k, v in zip(names, st[:6])}
 

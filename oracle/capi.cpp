@@ -277,7 +277,7 @@ int orc_generate(const void* rs32, const void* fs112, const int32_t* cfg5, int n
 // Adds `spp` samples (starting at FrameState.Frames) into sum (W*H*4 floats).
 // stats8 = {extend_rays, shadow_rays, extend_steps, extend_tris, shadow_steps, shadow_tris, 0, 0}
 // traversal: 0 literal C#, 1 canonical.  max_groups > 0 limits the run to the first local pixel groups.
-int orc_render(void* h, const void* rs32, const void* fs112, const int32_t* cfg5, int spp, float* sum, uint64_t* stats8, int traversal, int threads, int max_groups) {
+int orc_render(void* h, const void* rs32, const void* fs112, const int32_t* cfg5, int spp, float* sum, uint64_t* stats8, int traversal, int threads, int max_groups, int group_stride) {
     ORC_TRY
     OrcScene* s = (OrcScene*)h;
     RenderState rs;
@@ -295,7 +295,7 @@ int orc_render(void* h, const void* rs32, const void* fs112, const int32_t* cfg5
         for (int t = a; t < b; t++) {
             for (int c = t; c < nchunks; c += std::max(1, threads)) {
                 uint32_t g0 = (uint32_t)((uint64_t)localGroups * c / nchunks), g1 = (uint32_t)((uint64_t)localGroups * (c + 1) / nchunks);
-                RenderSamples(s->scene, s->lights, rs, fs, cfg, spp, sum, g0, g1, &st[c], traversal);
+                RenderSamples(s->scene, s->lights, rs, fs, cfg, spp, sum, g0, g1, &st[c], traversal, (uint32_t)std::max(1, group_stride));
             }
         }
     });

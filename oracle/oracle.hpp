@@ -219,6 +219,6 @@ struct RenderStats { uint64_t extend_rays = 0, shadow_rays = 0; TraversalStats e
 // Rows [row0,row1) of 8x8 pixel groups are rendered (row blocks for threading).
 void RenderSamples(const Scene& scene, const LightTable& lights, const RenderState& rs, FrameState fs,
                    const PathConfig& cfg, int spp, float* sum, uint32_t group0, uint32_t group1,
-                   RenderStats* stats, int traversal /*0 literal,1 canonical*/);
+                   RenderStats* stats, int traversal /*0 literal,1 canonical*/, uint32_t group_stride = 1);
 
 }  // namespace oracle

@@ -291,11 +291,13 @@ static int pickLight(const LightTable& lt, float r) {
 }
 
 void RenderSamples(const Scene& scene, const LightTable& lights, const RenderState& rs, FrameState fs, const PathConfig& cfg,
-                   int spp, float* sum, uint32_t group0, uint32_t group1, RenderStats* stats, int traversal) {
+                   int spp, float* sum, uint32_t group0, uint32_t group1, RenderStats* stats, int traversal, uint32_t group_stride) {
     const Accelerator& acc = scene.accelerator;
     const Vec4 sky = ld4(rs.SkyColor);
+    if (group_stride == 0) group_stride = 1;
     for (int s = 0; s < spp; s++, fs.Frames++, fs.Samples++) {
         for (uint32_t index = group0 * 64u; index < group1 * 64u; index++) {
+            if ((index >> 6) % group_stride != 0) continue;   // sub-sampled runs trace every n-th pixel group
             Vec3 o, d;
             uint32_t pixel, gidx;
             if (!pixelOfIndex(index, rs.Width, rs.Height, cfg.tile_rank, cfg.tile_world, &pixel, &gidx)) continue;
