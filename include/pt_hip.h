@@ -118,6 +118,11 @@ int pt_trace_occluded(pt_ctx* ctx, const float* o_d, const float* tmax, int32_t 
  * rays back: o_d n x 6, pixel n (0xFFFFFFFF where the thread emits no ray).  Parity/debug entry. */
 int pt_generate_rays(pt_ctx* ctx, const void* frame_state112, int32_t n, float* o_d, uint32_t* pixel);
 
+/* Measurement entry (no reference counterpart): uploads n rays once, runs the extend stage alone over them `iters`
+ * times exactly as pt_render launches it, and returns the mean launch time from events on the context's stream.
+ * tri / t (may be NULL) receive the hits of the last launch. */
+int pt_bench_extend(pt_ctx* ctx, const float* o_d, int32_t n, int32_t iters, float* avg_ms, int32_t* tri, float* t);
+
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
 int pt_reset_stats(pt_ctx* ctx);
 

@@ -98,7 +98,7 @@ uint32_t chooseBatch(const pt_ctx* c, uint32_t spp) {
     uint32_t want = (uint32_t)c->cfg.samples_per_batch;
     if (want == 0) {
         // enough paths per launch to fill 256 CUs x 32 waves several times over
-        const uint32_t target = 4u << 20;
+        const uint32_t target = 32u << 20;
         want = std::max(1u, target / std::max(1u, c->slots));
         want = std::min(want, 64u);
     }
@@ -210,7 +210,7 @@ int pt_create(const pt_config* cfg, pt_ctx** out) {
     c->grid_extend = c->num_cu * perCu;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_connect<false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
     c->grid_connect = c->num_cu * perCu;
-    c->grid_shade = c->num_cu * 8;
+    c->grid_shade = c->num_cu * 4;
     *out = c;
     return PT_OK;
 }
@@ -388,10 +388,12 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
         rp.frames0 = (uint32_t)fs.frames + s0;
         rp.samples = ns;
         HIPCHECK(c, hipMemsetAsync(c->q.plane, 0, (size_t)total * sizeof(float4), c->stream));
-        hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, 0ull);
+        const bool dense = (c->width % 8 == 0) && (c->height % 8 == 0);
+        hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, dense ? total : 0u, 0ull);
         {
             StageTimer t(c, 0);
-            hipLaunchKernelGGL(k_generate, dim3(launchGrid(total)), dim3(PT_BLOCK), 0, c->stream, rp, c->q, c->d_ctl);
+            if (dense) hipLaunchKernelGGL(k_generate<true>, dim3(launchGrid(total)), dim3(PT_BLOCK), 0, c->stream, rp, c->q, c->d_ctl);
+            else hipLaunchKernelGGL(k_generate<false>, dim3(launchGrid(total)), dim3(PT_BLOCK), 0, c->stream, rp, c->q, c->d_ctl);
             c->host_stats.generate_launches++;
         }
         if (generate_only) break;
@@ -407,7 +409,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             }
             {
                 StageTimer t(c, 2);
-                hipLaunchKernelGGL(k_shade, dim3(c->grid_shade), dim3(PT_BLOCK), 0, c->stream, c->sc, rp, c->q, c->d_ctl, cur);
+                hipLaunchKernelGGL(k_shade, dim3(c->grid_shade), dim3(PT_SHADE_BLOCK), 0, c->stream, c->sc, rp, c->q, c->d_ctl, cur);
                 c->host_stats.shade_launches++;
             }
             if (rp.nee && c->sc.n_lights > 0) {
@@ -567,6 +569,50 @@ int pt_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, float* o_
     }
     // the debug batch must not count as rendered samples
     HIPCHECK(c, hipMemset(c->d_ctl, 0, offsetof(Ctl, paths)));
+    return PT_OK;
+}
+
+int pt_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t iters, float* avg_ms, int32_t* tri, float* t) {
+    if (!c || !o_d || n <= 0 || iters <= 0 || !avg_ms) return PT_E_INVALID_ARG;
+    if (!c->has_scene) FAIL(c, PT_E_STATE, "pt_bench_extend before pt_upload_scene");
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if ((uint32_t)n > c->capacity) { int rc = allocQueues(c, (uint32_t)n); if (rc != PT_OK) return rc; }
+    std::vector<float4> o((size_t)n), d((size_t)n);
+    for (int i = 0; i < n; i++) {
+        o[i] = make_float4(o_d[6 * i], o_d[6 * i + 1], o_d[6 * i + 2], 0.0f);
+        d[i] = make_float4(o_d[6 * i + 3], o_d[6 * i + 4], o_d[6 * i + 5], 0.0f);
+    }
+    HIPCHECK(c, hipMemcpy(c->q.o[0], o.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    HIPCHECK(c, hipMemcpy(c->q.d[0], d.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    hipEvent_t a = getEvent(c), b = getEvent(c);
+    if (!a || !b) FAIL(c, PT_E_HIP, "pt_bench_extend: no events");
+    float total = 0.0f;
+    const bool stats = c->cfg.traversal_stats != 0;
+    for (int it = 0; it < iters + 1; it++) {   // the first launch warms caches and is not counted
+        hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, (uint32_t)n, 0ull);
+        HIPCHECK(c, hipEventRecord(a, c->stream));
+        if (stats) hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, 0);
+        else hipLaunchKernelGGL(k_extend<false>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, 0);
+        HIPCHECK(c, hipEventRecord(b, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        float ms = 0.0f;
+        HIPCHECK(c, hipEventElapsedTime(&ms, a, b));
+        if (it > 0) total += ms;
+    }
+    c->pool.push_back(a);
+    c->pool.push_back(b);
+    *avg_ms = total / (float)iters;
+    if (tri || t) {
+        std::vector<float4> h((size_t)n);
+        HIPCHECK(c, hipMemcpy(h.data(), c->q.hit, (size_t)n * 16, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) {
+            if (t) t[i] = h[i].x;
+            if (tri) memcpy(&tri[i], &h[i].y, 4);
+        }
+    }
+    hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, 0ull);
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
     return PT_OK;
 }
 

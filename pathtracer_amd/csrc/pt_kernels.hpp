@@ -5,6 +5,7 @@
 #include "pt_device.hpp"
 
 #define PT_BLOCK 256
+#define PT_SHADE_BLOCK 512
 
 // A slab distance can be NaN only for a ray with a zero/denormal/non-finite direction
 // component or a non-finite origin; such rays take the NaN-rejecting traversal.
@@ -41,6 +42,9 @@ struct Queues {
 
 // ------------------------------------------------------------------ generate
 // generate.glsl:135-156, 170-200.  Thread k of the batch: sample k / slots, local slot k % slots.
+// DENSE (image sides divisible by 8: every thread emits a ray) writes ray k to queue slot k and
+// needs no counter; otherwise the rays are appended by wave-level compaction.
+template <bool DENSE>
 __global__ void __launch_bounds__(PT_BLOCK) k_generate(RenderParams rp, Queues q, Ctl* ctl) {
     const uint32_t total = rp.slots * rp.samples;
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_generate(RenderParams rp, Queues q
         dir = normalize3(t - p);
         origin = p;
     }
-    const uint32_t out = waveAppend(valid, &ctl->count[0]);
+    const uint32_t out = DENSE ? k : waveAppend(valid, &ctl->count[0]);
     if (valid) {
         q.o[0][out] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(k));
         q.d[0][out] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(1u));
@@ -77,9 +81,48 @@ __global__ void __launch_bounds__(PT_BLOCK) k_generate(RenderParams rp, Queues q
     }
 }
 
+// Work distribution of the traversal kernels.  A launch is a fixed grid of persistent waves (no
+// host round trip to size it).  Wave w starts on chunk w (64 rays) with no atomic at all; waves
+// whose first chunk lies beyond the queue exit at once, so a nearly empty queue costs almost
+// nothing.  Further chunks come from a shared cursor, several at a time while many remain
+// (guided self-scheduling), so cheap (sky) and expensive rays balance across the chip while the
+// single cursor word stays far below its ~90 atomics/us limit.
+struct ChunkScheduler {
+    uint32_t nChunks, totalWaves, chunk, chunkEnd;
+    uint32_t* cursor;
+    __device__ __forceinline__ void init(uint32_t n, uint32_t* cursorWord) {
+        nChunks = (n + PT_WAVE - 1) / PT_WAVE;
+        totalWaves = gridDim.x * (blockDim.x / PT_WAVE);
+        chunk = blockIdx.x * (blockDim.x / PT_WAVE) + threadIdx.x / PT_WAVE;
+        chunkEnd = chunk + 1;
+        cursor = cursorWord;
+    }
+    __device__ __forceinline__ bool valid() const { return chunk < nChunks; }
+    // advance to the next chunk of this wave; false when the queue is exhausted
+    __device__ __forceinline__ bool next() {
+        if (++chunk < chunkEnd) return chunk < nChunks;
+        const uint32_t dynamic = nChunks > totalWaves ? nChunks - totalWaves : 0;
+        if (dynamic == 0) return false;
+        uint32_t got = 0, take = 1;
+        if (laneId() == 0) {
+            // a cheap, slightly stale look at the cursor sizes the request
+            const uint32_t seen = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t left = seen < dynamic ? dynamic - seen : 0;
+            take = left / (2 * totalWaves);
+            take = take < 1 ? 1 : (take > 16 ? 16 : take);
+            got = atomicAdd(cursor, take);
+        }
+        got = __shfl(got, 0);
+        take = __shfl(take, 0);
+        if (got >= dynamic) return false;
+        chunk = totalWaves + got;
+        chunkEnd = chunk + take;
+        return true;
+    }
+};
+
 // -------------------------------------------------------------------- extend
-// extend.glsl:301-309.  Persistent waves claim 64 rays at a time from a shared cursor, so
-// cheap (sky) and expensive rays balance across the chip without a host round trip.
+// extend.glsl:301-309.
 template <bool STATS>
 __global__ void __launch_bounds__(PT_BLOCK) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur) {
     __shared__ uint32_t lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
@@ -93,12 +136,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_extend(DevScene sc, Queues q, Ctl*
         atomicAdd(&ctl->extend_rays, (unsigned long long)n);
     }
     uint32_t steps = 0, tris = 0, overflow = 0;
-    while (true) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctl->cursor_extend, PT_WAVE);
-        base = __shfl(base, 0);
-        if (base >= n) break;
-        const uint32_t i = base + lane;
+    ChunkScheduler sched;
+    sched.init(n, &ctl->cursor_extend);
+    for (bool more = sched.valid(); more; more = sched.next()) {
+        const uint32_t i = sched.chunk * PT_WAVE + lane;
         if (i < n) {
             const float4 ro = q.o[cur][i], rd = q.d[cur][i];
             const f3 o = xyz(ro), d = xyz(rd);
@@ -127,12 +168,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_connect(DevScene sc, Queues q, Ctl
     const uint32_t lane = laneId();
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->shadow_rays, (unsigned long long)n);
     uint32_t steps = 0, tris = 0, overflow = 0;
-    while (true) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctl->cursor_connect, PT_WAVE);
-        base = __shfl(base, 0);
-        if (base >= n) break;
-        const uint32_t i = base + lane;
+    ChunkScheduler sched;
+    sched.init(n, &ctl->cursor_connect);
+    for (bool more = sched.valid(); more; more = sched.next()) {
+        const uint32_t i = sched.chunk * PT_WAVE + lane;
         if (i < n) {
             const float4 ro = q.so[i], rd = q.sd[i];
             const f3 o = xyz(ro), d = xyz(rd);
@@ -247,10 +286,32 @@ __device__ __forceinline__ int pickLight(const DevScene& sc, float r) {
     return lo;
 }
 
+// Dense output slot for every thread of the block with alive == true: wave ballots, a prefix
+// over the waves' counts in LDS, and ONE atomic per block (a single counter word sustains only
+// ~90 atomics/us, so per-wave atomics would bound the whole stage).  All threads of the block
+// must call it together.
+__device__ __forceinline__ uint32_t blockAppend(bool alive, uint32_t* counter, uint32_t* s_counts, uint32_t* s_base) {
+    const unsigned long long mask = __ballot(alive);
+    const uint32_t lane = laneId(), wave = threadIdx.x / PT_WAVE, nWaves = blockDim.x / PT_WAVE;
+    if (lane == 0) s_counts[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < nWaves; w++) { const uint32_t c = s_counts[w]; s_counts[w] = total; total += c; }
+        *s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t slot = *s_base + s_counts[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();
+    return slot;
+}
+
 // shade.glsl:349-459 plus next-event estimation.  Terminated paths add their radiance to
 // plane[birth] (one live path per birth index, so a plain read-modify-write is race free);
 // survivors are appended to the other queue by wave-level ballot/prefix compaction.
-__global__ void __launch_bounds__(PT_BLOCK) k_shade(DevScene sc, RenderParams rp, Queues q, Ctl* ctl, int cur) {
+__global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(DevScene sc, RenderParams rp, Queues q, Ctl* ctl, int cur) {
+    __shared__ uint32_t s_counts[2][PT_SHADE_BLOCK / PT_WAVE];
+    __shared__ uint32_t s_base[2];
     const uint32_t n = ctl->count[cur];
     const int nxt = cur ^ 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -390,13 +451,13 @@ __global__ void __launch_bounds__(PT_BLOCK) k_shade(DevScene sc, RenderParams rp
             }
             if (addIt) q.plane[birth] = to4(from4(q.plane[birth]) + add);
         }
-        const uint32_t slotOut = waveAppend(survive, &ctl->count[nxt]);
+        const uint32_t slotOut = blockAppend(survive, &ctl->count[nxt], s_counts[0], &s_base[0]);
         if (survive) {
             q.o[nxt][slotOut] = make_float4(newO.x, newO.y, newO.z, __uint_as_float(birth));
             q.d[nxt][slotOut] = make_float4(newD.x, newD.y, newD.z, __uint_as_float(newFlags));
             q.T[nxt][slotOut] = to4(newT);
         }
-        const uint32_t sOut = waveAppend(shadow, &ctl->shadow_count);
+        const uint32_t sOut = blockAppend(shadow, &ctl->shadow_count, s_counts[1], &s_base[1]);
         if (shadow) {
             q.so[sOut] = make_float4(sO.x, sO.y, sO.z, sTmax);
             q.sd[sOut] = make_float4(sD.x, sD.y, sD.z, __uint_as_float(birth));

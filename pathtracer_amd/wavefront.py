@@ -116,6 +116,15 @@ class Wavefront:
         self._check(self._lib.pt_generate_rays(self._h, _ptr(fs), n, _ptr(o_d), _ptr(pixel)))
         return o_d, pixel
 
+    def bench_extend(self, rays, iters=5):
+        """Mean launch time (ms) of the extend stage alone over `rays`, plus the hits of the last launch."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        ms = C.c_float()
+        tri, t = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        self._check(self._lib.pt_bench_extend(self._h, _ptr(rays), n, iters, C.byref(ms), _ptr(tri), _ptr(t)))
+        return ms.value, dict(tri=tri, t=t)
+
     def stats(self):
         s = _native.pt_stats()
         self._check(self._lib.pt_get_stats(self._h, C.byref(s)))
