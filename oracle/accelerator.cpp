@@ -162,11 +162,22 @@ void Accelerator::Intersect(const Ray& ray, Intersection& i) const {
 // the smallest triangle index.  The visiting order is the one the GPU kernels use, step for
 // step, so that distance culling (which compares box entry distances with triangle
 // distances, two differently rounded quantities) takes the same decisions on both sides:
-//   one step = one sibling pair; both children slab-tested; a child whose entry distance is
-//   beyond the best hit is skipped (tmin > best; a child entered exactly AT the best distance
-//   is still visited so an equal-distance triangle with a smaller index can win); hit leaf
-//   children are tested at once, left then right; of two hit interior children the nearer
-//   is visited next and the other pushed.
+//   a ray holds one current entry and a stack of entries; an entry is an interior reference
+//   (index of a left child) or a leaf.  Interior step: slab-test both children; drop a child whose
+//   entry distance is beyond the best hit (tmin > best; a child entered exactly AT the best
+//   distance is still visited so an equal-distance triangle with a smaller index can win); of two
+//   survivors the nearer becomes current and the other is pushed together with its entry
+//   distance; with none, pop.  Leaf step: test its triangles in index order, then pop.
+//   Pop (closest hit): entries whose recorded entry distance is now beyond the best hit are
+//   discarded unvisited.
+namespace {
+struct Entry { bool leaf; int first; int count; int node; float tmin; };
+inline Entry entryOf(const Node& n) {
+    if (n.Count > 0) return Entry{true, n.LeftFirst, n.Count, 0, 0.0f};
+    return Entry{false, 0, 0, n.LeftFirst, 0.0f};
+}
+}  // namespace
+
 static inline bool AcceptCanonical(const Triangle& t, const Ray& ray, Intersection& best, int j) {
     Intersection probe;
     probe.Distance = INF;
@@ -179,41 +190,66 @@ static inline bool AcceptCanonical(const Triangle& t, const Ray& ray, Intersecti
     return false;
 }
 
-void Accelerator::IntersectCanonical(const Ray& ray, Intersection& i, TraversalStats* st) const {
+// Shared walk.  anyHit: stop at the first accepted hit closer than tlimit and return true.
+static bool Walk(const Accelerator& acc, const Ray& ray, Intersection& i, bool anyHit, float tlimit, TraversalStats* st) {
+    const auto& nodes = acc.nodes;
+    const auto& triangles = acc.triangles;
     if (st) st->rays++;
-    if (nodes.empty()) return;
-    if (!BoxIntersect(nodes[0].Bounds, ray, nullptr, nullptr)) return;
-    auto testLeaf = [&](const Node& leaf) {
-        for (int j = leaf.LeftFirst; j < leaf.LeftFirst + leaf.Count; j++) {
-            if (st) st->tris++;
+    if (nodes.empty()) return false;
+    if (!BoxIntersect(nodes[0].Bounds, ray, nullptr, nullptr)) return false;
+    bool occluded = false;
+    auto testTriangle = [&](int j) {
+        if (st) st->tris++;
+        if (anyHit) {
+            Intersection probe;
+            probe.Distance = INF;
+            probe.Tri = -1;
+            if (TriangleIntersect(triangles[j], ray, probe, j) && probe.Distance < tlimit) occluded = true;
+        } else {
             AcceptCanonical(triangles[j], ray, i, j);
         }
     };
-    if (nodes[0].Count > 0) { testLeaf(nodes[0]); return; }
-    std::vector<int> stack;
-    int cur = nodes[0].LeftFirst;
-    while (true) {
+    std::vector<Entry> stack;
+    Entry cur = entryOf(nodes[0]);
+    auto pop = [&]() {
+        while (!stack.empty()) {
+            Entry e = stack.back();
+            stack.pop_back();
+            if (anyHit || !(e.tmin > i.Distance)) { cur = e; return true; }
+        }
+        return false;
+    };
+    for (;;) {
+        if (cur.leaf) {
+            for (int j = cur.first; j < cur.first + cur.count; j++) {
+                testTriangle(j);
+                if (occluded) return true;
+            }
+            if (!pop()) return false;
+            continue;
+        }
         if (st) st->steps++;
-        const Node& L = nodes[cur];
-        const Node& R = nodes[cur + 1];
+        const Node& L = nodes[cur.node];
+        const Node& R = nodes[cur.node + 1];
         float lt, rt;
         bool lhit = BoxIntersect(L.Bounds, ray, &lt, nullptr);
         bool rhit = BoxIntersect(R.Bounds, ray, &rt, nullptr);
-        lhit = lhit && !(lt > i.Distance);
-        rhit = rhit && !(rt > i.Distance);
-        if (lhit && L.Count > 0) { testLeaf(L); lhit = false; }
-        if (rhit && R.Count > 0) { testLeaf(R); rhit = false; }
+        if (anyHit) { lhit = lhit && lt < tlimit; rhit = rhit && rt < tlimit; }
+        else { lhit = lhit && !(lt > i.Distance); rhit = rhit && !(rt > i.Distance); }
+        Entry eL = entryOf(L), eR = entryOf(R);
+        eL.tmin = lt;
+        eR.tmin = rt;
         if (lhit && rhit) {
-            if (rt < lt) { stack.push_back(L.LeftFirst); cur = R.LeftFirst; }
-            else { stack.push_back(R.LeftFirst); cur = L.LeftFirst; }
-        } else if (lhit) cur = L.LeftFirst;
-        else if (rhit) cur = R.LeftFirst;
-        else {
-            if (stack.empty()) break;
-            cur = stack.back();
-            stack.pop_back();
-        }
+            if (rt < lt) { stack.push_back(eL); cur = eR; }
+            else { stack.push_back(eR); cur = eL; }
+        } else if (lhit) cur = eL;
+        else if (rhit) cur = eR;
+        else if (!pop()) return false;
     }
+}
+
+void Accelerator::IntersectCanonical(const Ray& ray, Intersection& i, TraversalStats* st) const {
+    Walk(*this, ray, i, false, INF, st);
 }
 
 void Accelerator::IntersectBrute(const Ray& ray, Intersection& i) const {
@@ -223,45 +259,10 @@ void Accelerator::IntersectBrute(const Ray& ray, Intersection& i) const {
 // Any accepted hit with 0 < t < tmax, visiting in the same order as IntersectCanonical;
 // children whose entry distance is not below tmax are skipped.
 bool Accelerator::Occluded(const Ray& ray, float tmax, TraversalStats* st) const {
-    if (st) st->rays++;
-    if (nodes.empty()) return false;
-    if (!BoxIntersect(nodes[0].Bounds, ray, nullptr, nullptr)) return false;
-    auto testLeaf = [&](const Node& leaf) {
-        for (int j = leaf.LeftFirst; j < leaf.LeftFirst + leaf.Count; j++) {
-            if (st) st->tris++;
-            Intersection probe;
-            probe.Distance = INF;
-            probe.Tri = -1;
-            if (TriangleIntersect(triangles[j], ray, probe, j) && probe.Distance < tmax) return true;
-        }
-        return false;
-    };
-    if (nodes[0].Count > 0) return testLeaf(nodes[0]);
-    std::vector<int> stack;
-    int cur = nodes[0].LeftFirst;
-    while (true) {
-        if (st) st->steps++;
-        const Node& L = nodes[cur];
-        const Node& R = nodes[cur + 1];
-        float lt, rt;
-        bool lhit = BoxIntersect(L.Bounds, ray, &lt, nullptr);
-        bool rhit = BoxIntersect(R.Bounds, ray, &rt, nullptr);
-        lhit = lhit && lt < tmax;
-        rhit = rhit && rt < tmax;
-        if (lhit && L.Count > 0) { if (testLeaf(L)) return true; lhit = false; }
-        if (rhit && R.Count > 0) { if (testLeaf(R)) return true; rhit = false; }
-        if (lhit && rhit) {
-            if (rt < lt) { stack.push_back(L.LeftFirst); cur = R.LeftFirst; }
-            else { stack.push_back(R.LeftFirst); cur = L.LeftFirst; }
-        } else if (lhit) cur = L.LeftFirst;
-        else if (rhit) cur = R.LeftFirst;
-        else {
-            if (stack.empty()) break;
-            cur = stack.back();
-            stack.pop_back();
-        }
-    }
-    return false;
+    Intersection unused;
+    unused.Distance = INF;
+    unused.Tri = -1;
+    return Walk(*this, ray, unused, true, tmax, st);
 }
 
 int Accelerator::MaxDepth() const {

@@ -28,7 +28,8 @@ class pt_stats(C.Structure):
                 ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("connect_launches", C.c_uint32),
                 ("generate_launches", C.c_uint32),
                 ("ms_generate", C.c_float), ("ms_extend", C.c_float), ("ms_shade", C.c_float), ("ms_connect", C.c_float),
-                ("ms_render", C.c_float), ("reserved", C.c_float * 3)]
+                ("ms_render", C.c_float), ("reserved", C.c_float * 3),
+                ("sched_interior", C.c_uint64), ("sched_leaf", C.c_uint64), ("sched_refill", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
@@ -66,7 +67,8 @@ def hip():
             import torch  # noqa: F401
         except ImportError:
             pass
-        lib = _load("libpt_hip.so")
+        # PT_HIP_LIB selects another build of the same library (kernel tuning experiments)
+        lib = _load(os.environ.get("PT_HIP_LIB", "libpt_hip.so"))
         vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
         lib.pt_last_error.restype = C.c_char_p
         lib.pt_last_error.argtypes = [vp]

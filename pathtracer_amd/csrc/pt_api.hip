@@ -509,14 +509,16 @@ static int traceCommon(pt_ctx* c, bool anyhit, const float* o_d, const float* tm
         TRY(hipMalloc((void**)&d_tmax, (size_t)n * 4));
         TRY(hipMalloc((void**)&d_occ, (size_t)n));
         TRY(hipMemcpyAsync(d_tmax, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_trace<true>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, d_rays, d_tmax, n, nullptr, nullptr, nullptr, d_occ, c->d_ctl);
+        TraceSource src{d_rays, d_tmax, nullptr, nullptr, nullptr, d_occ};
+        hipLaunchKernelGGL(k_trace<true>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl);
         TRY(hipGetLastError());
         TRY(hipMemcpyAsync(occ, d_occ, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     } else {
         TRY(hipMalloc((void**)&d_tri, (size_t)n * 4));
         TRY(hipMalloc((void**)&d_t, (size_t)n * 4));
         if (uv) TRY(hipMalloc((void**)&d_uv, (size_t)n * 8));
-        hipLaunchKernelGGL(k_trace<false>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, d_rays, nullptr, n, d_tri, d_t, d_uv, nullptr, c->d_ctl);
+        TraceSource src{d_rays, nullptr, d_tri, d_t, d_uv, nullptr};
+        hipLaunchKernelGGL(k_trace<false>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl);
         TRY(hipGetLastError());
         if (tri) TRY(hipMemcpyAsync(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         if (t) TRY(hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -631,6 +633,9 @@ int pt_get_stats(pt_ctx* c, pt_stats* out) {
     s.shadow_steps = ctl.shadow_steps;
     s.shadow_tris = ctl.shadow_tris;
     s.stack_overflows = ctl.stack_overflows;
+    s.sched_interior = ctl.sched_interior;
+    s.sched_leaf = ctl.sched_leaf;
+    s.sched_refill = ctl.sched_refill;
     *out = s;
     return PT_OK;
 }

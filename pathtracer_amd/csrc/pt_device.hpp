@@ -7,10 +7,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define PT_WAVE 64
-#define PT_STACK_LDS 16      // traversal stack entries kept in LDS per lane
-#define PT_STACK_SPILL 48    // further entries in per-lane scratch
+#define PT_STACK_LDS 9       // traversal stack entries (8 bytes each) kept in LDS per lane
+#define PT_STACK_SPILL 55    // further entries in per-lane scratch
 #define PT_STACK_TOTAL (PT_STACK_LDS + PT_STACK_SPILL)
 #define PT_EPSILON 0.00001f  // extend.glsl:4 / shade.glsl:4
 #define PT_PI 3.14159274101257324f
@@ -67,6 +68,7 @@ struct Ctl {
     uint32_t cursor_connect;
     uint32_t pad[3];
     unsigned long long paths, extend_rays, shadow_rays, extend_steps, extend_tris, shadow_steps, shadow_tris, stack_overflows;
+    unsigned long long sched_interior, sched_leaf, sched_refill;   // wave iterations by kind, extend stage, instrumented builds
 };
 
 // ------------------------------------------------ deterministic elementary fns
@@ -188,6 +190,15 @@ __device__ __forceinline__ void waveAdd64(unsigned long long* counter, uint32_t 
     if (laneId() == 0) atomicAdd(counter, total);
 }
 
+// A slab distance can be NaN only for a ray with a zero/denormal/non-finite direction
+// component or a non-finite origin; such rays take the NaN-rejecting traversal.
+__device__ __forceinline__ bool raySpecial(f3 o, f3 d) {
+    const bool dOk = fabsf(d.x) >= 1.0e-37f && fabsf(d.x) <= 3.0e38f && fabsf(d.y) >= 1.0e-37f && fabsf(d.y) <= 3.0e38f &&
+                     fabsf(d.z) >= 1.0e-37f && fabsf(d.z) <= 3.0e38f;
+    const bool oOk = fabsf(o.x) <= 3.0e38f && fabsf(o.y) <= 3.0e38f && fabsf(o.z) <= 3.0e38f;
+    return !(dOk && oOk);
+}
+
 // ------------------------------------------------------------------ traversal
 struct HitRec { float t; int32_t tri; float u, v; };
 
@@ -232,89 +243,226 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
     return t > 0.0f;
 }
 
-// Closest hit (ANYHIT = false) or any hit closer than tlimit (ANYHIT = true) for one ray per lane.
+// ---------------------------------------------------------------------------------------------
+// Per-ray traversal (the order every result depends on; the CPU oracle restates it step for step)
 //
-// One step = one 64-byte sibling-pair fetch.  Both children are slab-tested; a child is
-// skipped when its entry distance lies beyond the best hit (closest: tmin > best, so a
-// child entered exactly at the best distance is still visited and an equal-distance
-// triangle with a smaller index can win; any-hit: tmin >= tlimit).  Hit leaf children
-// are tested at once, left then right; of two hit interior children the nearer is
-// visited next and the other pushed.  Closest-hit ties go to the smaller triangle index.
-// The stack holds node indices of left children: PT_STACK_LDS entries per lane in LDS
-// (lstack[e * 64 + lane], conflict free), the rest in scratch.
-template <bool NANSAFE, bool ANYHIT, bool STATS>
-__device__ __forceinline__ bool traverseScene(const DevScene& sc, f3 o, f3 d, float tlimit, HitRec* hit, uint32_t* lstack,
-                                              uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow) {
-    float best = tlimit;
-    int32_t bestTri = -1;
-    float bu = 0.0f, bv = 0.0f;
-    bool occluded = false;
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // Ray.cs:18
-    const uint32_t lane = laneId();
-    uint32_t spill[PT_STACK_SPILL];
+//   A ray holds one current entry `cur` and a stack of entries.  An entry is either an interior
+//   reference (node index of a left child; the pair cur, cur+1 is one 64-byte record) or a leaf
+//   (first triangle, count) packed into 32 bits.
+//   Interior step: fetch the pair, slab-test both children, drop a child whose entry distance lies
+//   beyond the best hit (closest: tmin > best, so a child entered exactly at the best distance is
+//   still visited and an equal-distance triangle with a smaller index can win; any-hit:
+//   tmin >= tlimit).  Of two surviving children the nearer becomes `cur`, the other is pushed;
+//   with none, `cur` is popped (the ray ends on an empty stack).  Pushed entries carry their entry
+//   distance; a popped entry whose distance has meanwhile fallen beyond the best hit is discarded
+//   without being visited (closest hit only).
+//   Leaf step: test its triangles in index order, then pop.
+//   A packed leaf holds count-1 in 4 bits and the first triangle in 27; a leaf that does not fit
+//   (more than 15 triangles, or first >= 2^27) is entered through its node index instead and
+//   reads (first, count) back from the node record.
+//   Closest-hit ties go to the smaller triangle index.
+//
+// Per-wave scheduling (free to change: it cannot alter any ray's result)
+//
+//   Each iteration of the wave does ONE kind of work under a wave-uniform branch: an interior
+//   step for every lane holding an interior entry, or one triangle test for every lane holding a
+//   leaf.  Lanes that reach a leaf wait until PT_LEAF_BATCH lanes are waiting (or nobody is left
+//   stepping), so both code paths run with many lanes active instead of a few.
+//   Lanes are persistent: a lane whose ray has ended stores the result and takes the next ray of
+//   the wave's private range; the range is replenished 256 rays at a time from the shared cursor
+//   (first range static, no atomic), so long rays do not hold 63 finished lanes hostage and the
+//   single cursor word sees one atomic per 256 rays.
+//   The stack keeps PT_STACK_LDS entries (entry, distance: 8 bytes) per lane in LDS
+//   (lstack[e * 64 + lane]: conflict free), deeper entries in scratch.
+#define PT_LEAF_FLAG 0x80000000u
+#define PT_LEAF_MAX_COUNT 15
+#define PT_LEAF_MAX_FIRST (1u << 27)
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 16
+#endif
+#ifndef PT_LEAF_BATCH
+#define PT_LEAF_BATCH 12
+#endif
+#define PT_NO_RAY 0xFFFFFFFFu
 
-    auto testLeaf = [&](int32_t first, int32_t count) {
-        for (int32_t j = first; j < first + count; j++) {
-            const float4* p = sc.tri_hot + 3 * (size_t)j;
-            float4 q0 = p[0], q1 = p[1], q2 = p[2];
-            if (STATS) (*ntris)++;
-            float t, u, v;
-            if (triangleTest(q0, q1, q2, o, d, &t, &u, &v)) {
-                if (ANYHIT) {
-                    if (t < tlimit) { occluded = true; return; }
-                } else if (t < best || (t == best && j < bestTri)) {
-                    best = t; bestTri = j; bu = u; bv = v;
-                }
+// entry of the leaf child stored at node index `node` with triangles [first, first+count)
+__device__ __forceinline__ uint32_t packLeaf(int32_t first, int32_t count, int32_t node) {
+    if (count <= PT_LEAF_MAX_COUNT && (uint32_t)first < PT_LEAF_MAX_FIRST) return PT_LEAF_FLAG | ((uint32_t)(count - 1) << 27) | (uint32_t)first;
+    return PT_LEAF_FLAG | (15u << 27) | (uint32_t)node;
+}
+
+enum { PT_MODE_INTERIOR = 0, PT_MODE_LEAF = 1, PT_MODE_DONE = 2 };
+
+// stack and entry handling, written as macros over the locals of traverseWave so that every
+// piece of per-ray state stays in registers
+#define PT_PUSH(e, t)                                                                \
+    do {                                                                             \
+        if (sp < PT_STACK_LDS) { lstack[sp * PT_WAVE + lane] = make_uint2((e), __float_as_uint(t)); sp++; } \
+        else if (sp < PT_STACK_TOTAL) { spill[sp - PT_STACK_LDS] = (e); spillT[sp - PT_STACK_LDS] = (t); sp++; } \
+        else (*overflow)++; /* the subtree is dropped; counted, never silent */      \
+    } while (0)
+#define PT_ENTER(e)                                                                  \
+    do {                                                                             \
+        const uint32_t e_ = (e);                                                     \
+        if (e_ & PT_LEAF_FLAG) {                                                     \
+            const uint32_t low_ = e_ & (PT_LEAF_MAX_FIRST - 1u), cm1_ = (e_ >> 27) & 15u; \
+            if (cm1_ < 15u) { leafJ = (int32_t)low_; leafEnd = leafJ + (int32_t)cm1_ + 1; } \
+            else { /* big leaf: node `low_` is half of pair record (low_-1)/2 */     \
+                const float4 rec_ = sc.pairs[2 * (size_t)(low_ - 1u) + 1];           \
+                leafJ = __float_as_int(rec_.z);                                      \
+                leafEnd = leafJ + __float_as_int(rec_.w);                            \
+            }                                                                        \
+            mode = PT_MODE_LEAF;                                                     \
+        } else {                                                                     \
+            curNode = (int32_t)e_;                                                   \
+            mode = PT_MODE_INTERIOR;                                                 \
+        }                                                                            \
+    } while (0)
+// pops until an entry whose entry distance is not beyond the best hit turns up (closest hit only:
+// an any-hit limit never shrinks, so everything pushed stays eligible)
+#define PT_POP_OR_END()                                                              \
+    do {                                                                             \
+        mode = PT_MODE_DONE;                                                         \
+        while (sp > 0) {                                                             \
+            sp--;                                                                    \
+            uint32_t top_;                                                           \
+            float topT_;                                                             \
+            if (sp < PT_STACK_LDS) { const uint2 r_ = lstack[sp * PT_WAVE + lane]; top_ = r_.x; topT_ = __uint_as_float(r_.y); } \
+            else { top_ = spill[sp - PT_STACK_LDS]; topT_ = spillT[sp - PT_STACK_LDS]; } \
+            if (ANYHIT || !(topT_ > best)) { PT_ENTER(top_); break; }                \
+        }                                                                            \
+    } while (0)
+#define PT_TEST_TRIANGLE(j_)                                                         \
+    do {                                                                             \
+        const int32_t tj_ = (j_);                                                    \
+        const float4* tp_ = sc.tri_hot + 3 * (size_t)tj_;                            \
+        const float4 q0_ = tp_[0], q1_ = tp_[1], q2_ = tp_[2];                       \
+        if (STATS) (*ntris)++;                                                       \
+        float tt_, tu_, tv_;                                                         \
+        if (triangleTest(q0_, q1_, q2_, o, d, &tt_, &tu_, &tv_)) {                   \
+            if (ANYHIT) { if (tt_ < tlimit) occluded = true; }                       \
+            else if (tt_ < best || (tt_ == best && tj_ < bestTri)) { best = tt_; bestTri = tj_; bu = tu_; bv = tv_; } \
+        }                                                                            \
+    } while (0)
+
+// one interior step of the lanes selected by `active`
+#define PT_INTERIOR_STEP(NANSAFE_)                                                                   \
+    do {                                                                                             \
+        if (STATS) (*nsteps)++;                                                                      \
+        const float4* p_ = sc.pairs + 2 * (size_t)(curNode - 1); /* pair (curNode-1)/2 */            \
+        const float4 a_ = p_[0], b_ = p_[1], c_ = p_[2], e_ = p_[3];                                 \
+        float lt_, rt_;                                                                              \
+        bool lhit_ = slabTest<NANSAFE_>(a_.x, a_.y, a_.z, a_.w, b_.x, b_.y, o, inv, &lt_);           \
+        bool rhit_ = slabTest<NANSAFE_>(c_.x, c_.y, c_.z, c_.w, e_.x, e_.y, o, inv, &rt_);           \
+        if (ANYHIT) { lhit_ = lhit_ && lt_ < tlimit; rhit_ = rhit_ && rt_ < tlimit; }                \
+        else { lhit_ = lhit_ && !(lt_ > best); rhit_ = rhit_ && !(rt_ > best); }                     \
+        const int32_t lfirst_ = __float_as_int(b_.z), lcount_ = __float_as_int(b_.w);                \
+        const int32_t rfirst_ = __float_as_int(e_.z), rcount_ = __float_as_int(e_.w);                \
+        const uint32_t eL_ = lcount_ > 0 ? packLeaf(lfirst_, lcount_, curNode) : (uint32_t)lfirst_;  \
+        const uint32_t eR_ = rcount_ > 0 ? packLeaf(rfirst_, rcount_, curNode + 1) : (uint32_t)rfirst_; \
+        if (lhit_ && rhit_) {                                                                        \
+            if (rt_ < lt_) { PT_PUSH(eL_, lt_); PT_ENTER(eR_); }                                     \
+            else { PT_PUSH(eR_, rt_); PT_ENTER(eL_); }                                               \
+        } else if (lhit_) PT_ENTER(eL_);                                                             \
+        else if (rhit_) PT_ENTER(eR_);                                                               \
+        else PT_POP_OR_END();                                                                        \
+    } while (0)
+
+// Source: struct with
+//   void load(uint32_t i, f3* o, f3* d, float* tlimit) const   — ray i of the queue
+//   void store(uint32_t i, const HitRec& h, bool occluded) const
+template <bool ANYHIT, bool STATS, class Source>
+__device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, const Source& src,
+                                             uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched) {
+    // sched[0..2] (STATS builds): wave iterations spent on interior steps, leaf steps, retire/refill
+    const uint32_t lane = laneId();
+    const uint32_t totalWaves = gridDim.x * (blockDim.x / PT_WAVE);
+    const uint32_t waveId = blockIdx.x * (blockDim.x / PT_WAVE) + threadIdx.x / PT_WAVE;
+    const uint32_t grab = (cursor != nullptr && n >= totalWaves * 256u) ? 256u : 64u;
+    const uint32_t dynBase = totalWaves * grab;
+    uint32_t rangeLo = waveId * grab, rangeHi = rangeLo + grab;
+    if (rangeLo > n) rangeLo = n;
+    if (rangeHi > n) rangeHi = n;
+    bool exhausted = (cursor == nullptr) || dynBase >= n;
+
+    uint32_t rayIdx = PT_NO_RAY;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0);
+    float best = PT_INF, bu = 0.0f, bv = 0.0f, tlimit = PT_INF;
+    int32_t bestTri = -1;
+    bool occluded = false, special = false;
+    int mode = PT_MODE_DONE;
+    int32_t curNode = 0, leafJ = 0, leafEnd = 0;
+    int sp = 0;
+    uint32_t spill[PT_STACK_SPILL];
+    float spillT[PT_STACK_SPILL];
+
+    for (;;) {
+        const unsigned long long interiorMask = __ballot(mode == PT_MODE_INTERIOR);
+        const unsigned long long leafMask = __ballot(mode == PT_MODE_LEAF);
+        const uint32_t nActive = (uint32_t)__popcll(interiorMask | leafMask);
+        const bool anyFinished = __ballot(rayIdx != PT_NO_RAY && mode == PT_MODE_DONE) != 0ull;
+        const bool moreRays = !(exhausted && rangeLo == rangeHi);
+        if (nActive == 0u || (64u - nActive >= PT_REFILL_MIN && (anyFinished || moreRays))) {
+            // ---- retire finished rays, hand the idle lanes the next rays
+            if (STATS) sched[2]++;
+            if (rayIdx != PT_NO_RAY && mode == PT_MODE_DONE) {
+                HitRec h;
+                h.t = best; h.tri = bestTri; h.u = bu; h.v = bv;
+                src.store(rayIdx, h, occluded);
+                rayIdx = PT_NO_RAY;
+            }
+            if (rangeLo == rangeHi && !exhausted) {
+                uint32_t got = 0;
+                if (lane == 0) got = atomicAdd(cursor, grab);
+                got = __shfl(got, 0);
+                const uint32_t lo = dynBase + got;
+                if (lo >= n) exhausted = true;
+                else { rangeLo = lo; rangeHi = lo + grab < n ? lo + grab : n; }
+            }
+            const uint32_t avail = rangeHi - rangeLo;
+            if (avail == 0u) {
+                if (nActive == 0u) break;   // nothing in flight and nothing left to hand out
+                continue;
+            }
+            const unsigned long long idleMask = __ballot(rayIdx == PT_NO_RAY);
+            const uint32_t rank = (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
+            if (rayIdx == PT_NO_RAY && rank < avail) {
+                rayIdx = rangeLo + rank;
+                src.load(rayIdx, &o, &d, &tlimit);
+                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // Ray.cs:18
+                best = tlimit;
+                bestTri = -1;
+                bu = bv = 0.0f;
+                occluded = false;
+                sp = 0;
+                special = raySpecial(o, d);
+                float tr;
+                // the root test is done once per ray: always the NaN-propagating form
+                const bool in = sc.n_nodes > 0 &&
+                                slabTest<true>(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], o, inv, &tr);
+                if (!in) mode = PT_MODE_DONE;
+                else if (sc.root_count > 0) { leafJ = sc.root_left; leafEnd = sc.root_left + sc.root_count; mode = PT_MODE_LEAF; }
+                else { curNode = sc.root_left; mode = PT_MODE_INTERIOR; }
+            }
+            const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+            rangeLo += nIdle < avail ? nIdle : avail;
+            continue;
+        }
+        // ---- one kind of work for the whole wave
+        if (interiorMask != 0ull && (uint32_t)__popcll(leafMask) < PT_LEAF_BATCH) {
+            if (STATS) sched[0]++;
+            if (__any(mode == PT_MODE_INTERIOR && special)) {
+                if (mode == PT_MODE_INTERIOR) PT_INTERIOR_STEP(true);
+            } else {
+                if (mode == PT_MODE_INTERIOR) PT_INTERIOR_STEP(false);
+            }
+        } else {
+            if (STATS) sched[1]++;
+            if (mode == PT_MODE_LEAF) {
+                PT_TEST_TRIANGLE(leafJ);
+                if (ANYHIT && occluded) mode = PT_MODE_DONE;
+                else if (++leafJ == leafEnd) PT_POP_OR_END();
             }
         }
-    };
-
-    bool alive = sc.n_nodes > 0;
-    if (alive) {
-        float tr;
-        // the root test is done once per ray: always the NaN-propagating form
-        alive = slabTest<true>(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], o, inv, &tr);
     }
-    if (alive && sc.root_count > 0) {
-        testLeaf(sc.root_left, sc.root_count);
-        alive = false;
-    }
-    int32_t cur = sc.root_left;
-    int sp = 0;
-    while (alive) {
-        if (STATS) (*nsteps)++;
-        const float4* p = sc.pairs + 2 * (size_t)(cur - 1);   // pair (cur-1)/2, 4 float4 each
-        const float4 a = p[0], b = p[1], c = p[2], e = p[3];
-        float lt, rt;
-        bool lhit = slabTest<NANSAFE>(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, &lt);
-        bool rhit = slabTest<NANSAFE>(c.x, c.y, c.z, c.w, e.x, e.y, o, inv, &rt);
-        if (ANYHIT) { lhit = lhit && lt < tlimit; rhit = rhit && rt < tlimit; }
-        else { lhit = lhit && !(lt > best); rhit = rhit && !(rt > best); }
-        const int32_t lfirst = __float_as_int(b.z), lcount = __float_as_int(b.w);
-        const int32_t rfirst = __float_as_int(e.z), rcount = __float_as_int(e.w);
-        if (lhit && lcount > 0) { testLeaf(lfirst, lcount); lhit = false; }
-        if (ANYHIT && occluded) break;
-        if (rhit && rcount > 0) { testLeaf(rfirst, rcount); rhit = false; }
-        if (ANYHIT && occluded) break;
-        if (lhit && rhit) {
-            int32_t farChild, nearChild;
-            if (rt < lt) { nearChild = rfirst; farChild = lfirst; }
-            else { nearChild = lfirst; farChild = rfirst; }
-            if (sp < PT_STACK_LDS) lstack[sp * PT_WAVE + lane] = (uint32_t)farChild;
-            else if (sp < PT_STACK_TOTAL) spill[sp - PT_STACK_LDS] = (uint32_t)farChild;
-            else { (*overflow)++; sp--; }   // drop the far subtree; counted, never silent
-            sp++;
-            cur = nearChild;
-        } else if (lhit) {
-            cur = lfirst;
-        } else if (rhit) {
-            cur = rfirst;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            cur = (int32_t)((sp < PT_STACK_LDS) ? lstack[sp * PT_WAVE + lane] : spill[sp - PT_STACK_LDS]);
-        }
-    }
-    if (!ANYHIT) { hit->t = best; hit->tri = bestTri; hit->u = bu; hit->v = bv; }
-    return occluded;
 }

@@ -6,15 +6,9 @@
 
 #define PT_BLOCK 256
 #define PT_SHADE_BLOCK 512
-
-// A slab distance can be NaN only for a ray with a zero/denormal/non-finite direction
-// component or a non-finite origin; such rays take the NaN-rejecting traversal.
-__device__ __forceinline__ bool raySpecial(f3 o, f3 d) {
-    const bool dOk = fabsf(d.x) >= 1.0e-37f && fabsf(d.x) <= 3.0e38f && fabsf(d.y) >= 1.0e-37f && fabsf(d.y) <= 3.0e38f &&
-                     fabsf(d.z) >= 1.0e-37f && fabsf(d.z) <= 3.0e38f;
-    const bool oOk = fabsf(o.x) <= 3.0e38f && fabsf(o.y) <= 3.0e38f && fabsf(o.z) <= 3.0e38f;
-    return !(dOk && oOk);
-}
+#ifndef PT_TRAVERSE_WAVES
+#define PT_TRAVERSE_WAVES 5   // minimum waves per SIMD the traversal kernels are compiled for (caps their VGPRs)
+#endif
 
 struct RenderParams {
     int32_t width, height;
@@ -81,54 +75,30 @@ __global__ void __launch_bounds__(PT_BLOCK) k_generate(RenderParams rp, Queues q
     }
 }
 
-// Work distribution of the traversal kernels.  A launch is a fixed grid of persistent waves (no
-// host round trip to size it).  Wave w starts on chunk w (64 rays) with no atomic at all; waves
-// whose first chunk lies beyond the queue exit at once, so a nearly empty queue costs almost
-// nothing.  Further chunks come from a shared cursor, several at a time while many remain
-// (guided self-scheduling), so cheap (sky) and expensive rays balance across the chip while the
-// single cursor word stays far below its ~90 atomics/us limit.
-struct ChunkScheduler {
-    uint32_t nChunks, totalWaves, chunk, chunkEnd;
-    uint32_t* cursor;
-    __device__ __forceinline__ void init(uint32_t n, uint32_t* cursorWord) {
-        nChunks = (n + PT_WAVE - 1) / PT_WAVE;
-        totalWaves = gridDim.x * (blockDim.x / PT_WAVE);
-        chunk = blockIdx.x * (blockDim.x / PT_WAVE) + threadIdx.x / PT_WAVE;
-        chunkEnd = chunk + 1;
-        cursor = cursorWord;
+// -------------------------------------------------------------------- extend
+// extend.glsl:301-309: closest hit for every ray of the current queue.  A fixed grid of
+// persistent waves (no host round trip to size the launch); see traverseWave for how rays are
+// handed to lanes.
+struct ExtendSource {
+    const float4* o;
+    const float4* d;
+    float4* hit;
+    __device__ __forceinline__ void load(uint32_t i, f3* ro, f3* rd, float* tlimit) const {
+        const float4 a = o[i], b = d[i];
+        *ro = xyz(a);
+        *rd = xyz(b);
+        *tlimit = PT_INF;
     }
-    __device__ __forceinline__ bool valid() const { return chunk < nChunks; }
-    // advance to the next chunk of this wave; false when the queue is exhausted
-    __device__ __forceinline__ bool next() {
-        if (++chunk < chunkEnd) return chunk < nChunks;
-        const uint32_t dynamic = nChunks > totalWaves ? nChunks - totalWaves : 0;
-        if (dynamic == 0) return false;
-        uint32_t got = 0, take = 1;
-        if (laneId() == 0) {
-            // a cheap, slightly stale look at the cursor sizes the request
-            const uint32_t seen = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t left = seen < dynamic ? dynamic - seen : 0;
-            take = left / (2 * totalWaves);
-            take = take < 1 ? 1 : (take > 16 ? 16 : take);
-            got = atomicAdd(cursor, take);
-        }
-        got = __shfl(got, 0);
-        take = __shfl(take, 0);
-        if (got >= dynamic) return false;
-        chunk = totalWaves + got;
-        chunkEnd = chunk + take;
-        return true;
+    __device__ __forceinline__ void store(uint32_t i, const HitRec& h, bool) const {
+        hit[i] = make_float4(h.t, __int_as_float(h.tri), h.u, h.v);
     }
 };
 
-// -------------------------------------------------------------------- extend
-// extend.glsl:301-309.
 template <bool STATS>
-__global__ void __launch_bounds__(PT_BLOCK) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur) {
-    __shared__ uint32_t lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
-    uint32_t* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
+__global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur) {
+    __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
+    uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
     const uint32_t n = ctl->count[cur];
-    const uint32_t lane = laneId();
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // counters of the stages that follow this launch
         ctl->count[cur ^ 1] = 0;
@@ -136,23 +106,20 @@ __global__ void __launch_bounds__(PT_BLOCK) k_extend(DevScene sc, Queues q, Ctl*
         atomicAdd(&ctl->extend_rays, (unsigned long long)n);
     }
     uint32_t steps = 0, tris = 0, overflow = 0;
-    ChunkScheduler sched;
-    sched.init(n, &ctl->cursor_extend);
-    for (bool more = sched.valid(); more; more = sched.next()) {
-        const uint32_t i = sched.chunk * PT_WAVE + lane;
-        if (i < n) {
-            const float4 ro = q.o[cur][i], rd = q.d[cur][i];
-            const f3 o = xyz(ro), d = xyz(rd);
-            HitRec h;
-            const bool special = raySpecial(o, d);
-            if (__any(special)) traverseScene<true, false, STATS>(sc, o, d, PT_INF, &h, lstack, &steps, &tris, &overflow);
-            else traverseScene<false, false, STATS>(sc, o, d, PT_INF, &h, lstack, &steps, &tris, &overflow);
-            q.hit[i] = make_float4(h.t, __int_as_float(h.tri), h.u, h.v);
-        }
-    }
+    ExtendSource src;
+    src.o = q.o[cur];
+    src.d = q.d[cur];
+    src.hit = q.hit;
+    uint32_t sched[3] = {0, 0, 0};
+    traverseWave<false, STATS>(sc, n, &ctl->cursor_extend, lstack, src, &steps, &tris, &overflow, sched);
     if (STATS) {
         waveAdd64(&ctl->extend_steps, steps);
         waveAdd64(&ctl->extend_tris, tris);
+        if (laneId() == 0) {
+            atomicAdd(&ctl->sched_interior, (unsigned long long)sched[0]);
+            atomicAdd(&ctl->sched_leaf, (unsigned long long)sched[1]);
+            atomicAdd(&ctl->sched_refill, (unsigned long long)sched[2]);
+        }
     }
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
 }
@@ -160,32 +127,39 @@ __global__ void __launch_bounds__(PT_BLOCK) k_extend(DevScene sc, Queues q, Ctl*
 // ------------------------------------------------------------------- connect
 // Shadow rays of next-event estimation (no reference counterpart).  Unoccluded rays add
 // their contribution to the path's radiance.
-template <bool STATS>
-__global__ void __launch_bounds__(PT_BLOCK) k_connect(DevScene sc, Queues q, Ctl* ctl) {
-    __shared__ uint32_t lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
-    uint32_t* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
-    const uint32_t n = ctl->shadow_count;
-    const uint32_t lane = laneId();
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->shadow_rays, (unsigned long long)n);
-    uint32_t steps = 0, tris = 0, overflow = 0;
-    ChunkScheduler sched;
-    sched.init(n, &ctl->cursor_connect);
-    for (bool more = sched.valid(); more; more = sched.next()) {
-        const uint32_t i = sched.chunk * PT_WAVE + lane;
-        if (i < n) {
-            const float4 ro = q.so[i], rd = q.sd[i];
-            const f3 o = xyz(ro), d = xyz(rd);
-            const bool special = raySpecial(o, d);
-            bool occ;
-            if (__any(special)) occ = traverseScene<true, true, STATS>(sc, o, d, ro.w, nullptr, lstack, &steps, &tris, &overflow);
-            else occ = traverseScene<false, true, STATS>(sc, o, d, ro.w, nullptr, lstack, &steps, &tris, &overflow);
-            if (!occ) {
-                const uint32_t birth = __float_as_uint(rd.w);
-                const f4 c = from4(q.sc[i]);
-                q.plane[birth] = to4(from4(q.plane[birth]) + c);
-            }
+struct ConnectSource {
+    const float4* so;
+    const float4* sd;
+    const float4* sc;
+    float4* plane;
+    __device__ __forceinline__ void load(uint32_t i, f3* ro, f3* rd, float* tlimit) const {
+        const float4 a = so[i], b = sd[i];
+        *ro = xyz(a);
+        *rd = xyz(b);
+        *tlimit = a.w;
+    }
+    __device__ __forceinline__ void store(uint32_t i, const HitRec&, bool occluded) const {
+        if (!occluded) {
+            const uint32_t birth = __float_as_uint(sd[i].w);
+            plane[birth] = to4(from4(plane[birth]) + from4(sc[i]));
         }
     }
+};
+
+template <bool STATS>
+__global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScene sc, Queues q, Ctl* ctl) {
+    __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
+    uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
+    const uint32_t n = ctl->shadow_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->shadow_rays, (unsigned long long)n);
+    uint32_t steps = 0, tris = 0, overflow = 0;
+    ConnectSource src;
+    src.so = q.so;
+    src.sd = q.sd;
+    src.sc = q.sc;
+    src.plane = q.plane;
+    uint32_t sched[3] = {0, 0, 0};
+    traverseWave<true, STATS>(sc, n, &ctl->cursor_connect, lstack, src, &steps, &tris, &overflow, sched);
     if (STATS) {
         waveAdd64(&ctl->shadow_steps, steps);
         waveAdd64(&ctl->shadow_tris, tris);
@@ -492,24 +466,34 @@ __global__ void __launch_bounds__(PT_BLOCK) k_assemble(const float4* gathered, u
 }
 
 // ------------------------------------------------------- standalone queries
-template <bool ANYHIT>
-__global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, const float* o_d, const float* tmax, int n, int32_t* tri, float* t, float* uv, uint8_t* occluded, Ctl* ctl) {
-    __shared__ uint32_t lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
-    uint32_t* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0, tris = 0, overflow = 0;
-    if (i < n) {
-        const f3 o = mk3(o_d[6 * i], o_d[6 * i + 1], o_d[6 * i + 2]), d = mk3(o_d[6 * i + 3], o_d[6 * i + 4], o_d[6 * i + 5]);
-        if (ANYHIT) {
-            occluded[i] = traverseScene<true, true, false>(sc, o, d, tmax[i], nullptr, lstack, &steps, &tris, &overflow) ? 1 : 0;
-        } else {
-            HitRec h;
-            traverseScene<true, false, false>(sc, o, d, PT_INF, &h, lstack, &steps, &tris, &overflow);
-            tri[i] = h.tri;
-            t[i] = h.t;
-            if (uv) { uv[2 * i] = h.u; uv[2 * i + 1] = h.v; }
-        }
+struct TraceSource {
+    const float* o_d;
+    const float* tmax;
+    int32_t* tri;
+    float* t;
+    float* uv;
+    uint8_t* occluded;
+    __device__ __forceinline__ void load(uint32_t i, f3* ro, f3* rd, float* tlimit) const {
+        *ro = mk3(o_d[6 * i], o_d[6 * i + 1], o_d[6 * i + 2]);
+        *rd = mk3(o_d[6 * i + 3], o_d[6 * i + 4], o_d[6 * i + 5]);
+        *tlimit = tmax ? tmax[i] : PT_INF;
     }
+    __device__ __forceinline__ void store(uint32_t i, const HitRec& h, bool occ) const {
+        if (occluded) occluded[i] = occ ? 1 : 0;
+        if (tri) tri[i] = h.tri;
+        if (t) t[i] = h.t;
+        if (uv) { uv[2 * i] = h.u; uv[2 * i + 1] = h.v; }
+    }
+};
+
+// One wave per 64 rays (grid sized by the caller), no shared cursor.
+template <bool ANYHIT>
+__global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src, int n, Ctl* ctl) {
+    __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
+    uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
+    uint32_t steps = 0, tris = 0, overflow = 0;
+    uint32_t sched[3] = {0, 0, 0};
+    traverseWave<ANYHIT, false>(sc, (uint32_t)n, nullptr, lstack, src, &steps, &tris, &overflow, sched);
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
 }
 

@@ -145,6 +145,55 @@ def test_tiny_and_empty_scenes(pa, ob):
     wf.close()
 
 
+def test_big_leaves(pa, ob):
+    """Coincident triangles cannot be split by SAH: leaves of 40 and 17 triangles (beyond the 15 a packed
+    stack entry holds) next to ordinary ones; ties among the copies go to the smallest index."""
+    rng = np.random.RandomState(3)
+    tris = np.zeros(40 + 17 + 200, ob.TRIANGLE)
+
+    def put(k, a, b, c):
+        n = np.cross(b - a, c - a)
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        for name, p in (("v1", a), ("v2", b), ("v3", c)):
+            tris[name]["position"][k] = p
+            tris[name]["normal"][k] = n
+    base = np.array([[0, 0, 0], [2, 0, 0], [0, 2, 0]], np.float32)
+    for k in range(40):
+        put(k, *base)
+    for k in range(40, 57):
+        put(k, *(base + np.float32([5, 0, 1])))
+    for k in range(57, tris.size):
+        c = rng.uniform(-6, 6, 3).astype(np.float32)
+        put(k, c, c + rng.uniform(-1, 1, 3).astype(np.float32), c + rng.uniform(-1, 1, 3).astype(np.float32))
+    s = ob.Scene("")
+    s.set_materials(np.zeros(1, ob.MATERIAL))
+    s.add_triangles(tris)
+    s.build()
+    mats, t2, nodes = s.arrays()
+    assert nodes["count"].max() >= 40 and (nodes["count"] == 17).any()
+    wf = pa.Wavefront()
+    wf.upload_scene(mats, t2, nodes)
+    n = 20000
+    o = rng.uniform(-8, 8, (n, 3)).astype(np.float32)
+    o[:, 2] = rng.uniform(2, 8, n)
+    tgt = rng.uniform(-1, 7, (n, 3)).astype(np.float32)
+    tgt[:, 2] = rng.uniform(-0.5, 1.5, n)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d.astype(np.float32)], 1)
+    g = wf.trace_closest(rays)
+    can = s.intersect(rays, "canonical")
+    br = s.intersect(rays, "brute")
+    lit = s.intersect(rays, "literal")
+    assert np.array_equal(g["tri"], can["tri"]) and np.array_equal(bits(g["t"]), bits(can["t"]))
+    assert np.array_equal(g["tri"], br["tri"]) and np.array_equal(bits(g["t"]), bits(lit["t"]))
+    big = (t2["v1"]["position"][g["tri"].clip(0)] == base[0]).all(axis=1) & (g["tri"] >= 0)
+    assert big.sum() > 100
+    tmax = rng.uniform(0.5, 12, n).astype(np.float32)
+    assert np.array_equal(wf.trace_occluded(rays, tmax), s.occluded(rays, tmax))
+    wf.close()
+
+
 def pa_assets():
     from conftest import MESHES
     return MESHES

@@ -77,6 +77,8 @@ def main():
     msg = f"extend: {ms:.3f} ms/launch, {rays.shape[0] / ms / 1e3:.1f} Mrays/s, hit fraction {(res['tri'] >= 0).mean():.3f}, checksum {digest}"
     if args.stats:
         msg += f", steps/ray {st['extend_steps'] / launches / rays.shape[0]:.2f}, tris/ray {st['extend_tris'] / launches / rays.shape[0]:.2f}"
+        msg += (f", interior lane use {st['extend_steps'] / max(1, 64 * st['sched_interior']):.2f}, leaf lane use {st['extend_tris'] / max(1, 64 * st['sched_leaf']):.2f}"
+                f", wave iterations/64 rays: interior {st['sched_interior'] * 64 / launches / rays.shape[0]:.1f} leaf {st['sched_leaf'] * 64 / launches / rays.shape[0]:.1f} refill {st['sched_refill'] * 64 / launches / rays.shape[0]:.1f}")
     print(msg, flush=True)
     assert st["stack_overflows"] == 0
     wf.close()
