@@ -1,0 +1,206 @@
+"""Host-side logic without a GPU: the C++ host mirror against the oracle, the C ABI's exported symbols,
+and the multi-rank tile path over gloo (world size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import MESHES, ROOT, bundled_view
+
+PKG = os.path.join(ROOT, "pathtracer_amd")
+
+
+@pytest.fixture(scope="module")
+def host():
+    from pathtracer_amd import host as h
+    return h
+
+
+def same(a, b):
+    return all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+
+
+def test_host_bundled_scene_matches_oracle(host, bundled):
+    for threads in (1, 8):
+        s = host.Scene()
+        s.initialize_scene(11)
+        s.build(threads)
+        assert same(s.arrays(), bundled.arrays())
+        assert s.counts()["depth"] == bundled.counts()["max_depth"]
+
+
+def test_host_other_seeds_and_rebuild(host, ob):
+    for seed in (1, 2024):
+        s, o = host.Scene(), ob.Scene(MESHES)
+        s.initialize_scene(seed)
+        o.initialize_scene(seed)
+        s.build(4)
+        o.build()
+        assert same(s.arrays(), o.arrays())
+    # Scene.Clear then a new scene (key P, Game.cs:169-180)
+    s.clear()
+    o.clear()
+    s.add_mesh("cube", True)
+    o.add_mesh("cube", True)
+    s.build()
+    o.build()
+    assert same(s.arrays(), o.arrays())
+
+
+def test_host_parallel_build_is_identical_on_soups(host, ob):
+    o = ob.Scene("")
+    o.soup(120000, seed=99)
+    o.build()
+    for threads in (1, 3, 8):
+        s = host.Scene("")
+        s.generate_soup(120000, seed=99)
+        s.build(threads)
+        assert same(s.arrays(), o.arrays()), threads
+
+
+def test_host_meshes_materials_floor(host, ob):
+    from pathtracer_amd import material, METAL
+    a, b = material((0.7, 0.7, 0.9, 0), type=METAL, roughness=0.1), material((0.7, 0.7, 0.9, 0), type=METAL, roughness=0.16)
+    rot = np.eye(4, dtype=np.float32)
+    rot[3, :3] = (1, 2, 3)
+    s, o = host.Scene(), ob.Scene(MESHES)
+    for sc, fl in ((s, s.generate_tiled_floor), (o, o.floor)):
+        sc.add_mesh("cornell")
+        sc.add_mesh("torus", True, rot, a)
+        fl(a, b)
+        sc.add_mesh("sphere", True, rot * np.float32(0.5), b)
+    s.build(2)
+    o.build()
+    assert same(s.arrays(), o.arrays())
+    assert s.get_material_index(a) == s.get_material_index(a.copy())
+    n = s.counts()["materials"]
+    assert s.get_material_index(material((0.1, 0.2, 0.3, 0))) == n   # a new one is appended
+
+
+def test_host_obj_text_loader(host, ob, tmp_path):
+    """The OBJ/MTL text path of the host mirror (Mesh.cs:72-329) on a file written here: quads, negative
+    indices, missing normals, tabs, a material library."""
+    (tmp_path / "m.mtl").write_text("newmtl red\n  Kd 0.8 0.1 0.1\n  Ke 0 0 0\nnewmtl lamp\n\tKa 0.2 0.2 0.2\n  Kd 1 1 1\n  Ke 3 2 1\n")
+    (tmp_path / "box.obj").write_text(
+        "# test\nmtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1.5\nv 1 0 1.5\nv 1 1 1.5\nv 0 1 1.5\n"
+        "vn 0 0 -1\ng bottom\nusemtl red\nf 1//1 2//1 3//1 4//1\ng top\nusemtl lamp\nf -4 -3 -2 -1\nf 1/1 2/1 6/1 5/1\n"
+        "usemtl missing\nf 2\t3 7 6\n")
+    s, o = host.Scene(str(tmp_path) + "/"), ob.Scene(str(tmp_path) + "/")
+    for sc in (s, o):
+        sc.add_mesh("box", True)
+        sc.build()
+    assert same(s.arrays(), o.arrays())
+    mats, tris, _ = s.arrays()
+    assert tris.size == 8 and mats.size == 3
+    assert mats["emissive"][1].tolist() == [3, 2, 1, 0]
+
+
+def test_host_camera_matches_oracle(host, bundled):
+    for (w, h) in ((512, 512), (1920, 1080)):
+        fs = host.Camera(w, h).frame_state((0, 2, 15), (0, 3, 0), frames=5, samples=5)
+        assert fs.tobytes() == bundled_view(bundled, w, h, frames=5).tobytes()
+    with pytest.raises(host.HostError):
+        host.Scene("/nonexistent/").add_mesh("cube")
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libpt_hip.so / libpt_host.so load without a GPU and export what include/*.h declares."""
+    for header, libname, prefix in (("pt_hip.h", "libpt_hip.so", "pt_"), ("pt_host.h", "libpt_host.so", "pth_")):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared = set(re.findall(r"\b(" + prefix + r"[a-z_0-9]+)\s*\(", text))
+        assert len(declared) >= 10
+        lib = ctypes.CDLL(os.path.join(PKG, libname))
+        for name in sorted(declared):
+            assert hasattr(lib, name), f"{libname} does not export {name}"
+    from pathtracer_amd import _native
+    assert set(_native.PT_HIP_SYMBOLS) == set(re.findall(r"\b(pt_[a-z_0-9]+)\s*\(", re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pt_hip.h")).read(), flags=re.S)))
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    from pathtracer_amd import _native
+    monkeypatch.setattr(_native, "_hip", None)
+    monkeypatch.setenv("PT_HIP_LIB", "libpt_hip_absent.so")
+    with pytest.raises(_native.NativeLibraryMissing):
+        _native.hip()
+    monkeypatch.setattr(_native, "_hip", None)
+
+
+def test_tile_partition_helpers():
+    from pathtracer_amd import tiles
+    own = tiles.tile_owner(40, 24, 3)
+    assert own.shape == (24, 40) and set(np.unique(own)) == {0, 1, 2}
+    assert (own[:8, :8] == 0).all() and (own[:8, 8:16] == 1).all() and (own[8:16, :8] == (5 % 3)).all()
+    total = sum(tiles.local_slots(40, 24, r, 3)[0] for r in range(3))
+    assert total == 5 * 3 * 64
+    assert len({tiles.local_slots(40, 24, r, 3)[1] for r in range(3)}) == 1
+
+
+WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+from oracle import binding as ob
+from pathtracer_amd import tiles
+from conftest import MESHES
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+w, h, spp = 72, 40, 2
+s = ob.Scene(MESHES); s.add_mesh("cornell"); s.build()
+fs, _ = s.camera((0, 1, 3.4), (0, 1, 0), w, h, use_scene=True, frames=1, samples=1)
+rs = ob.render_state(w, h, sky=(0.1, 0.2, 0.3, 1))
+# this rank's tiles only, laid out as the device accumulator is: slot = local group * 64 + lane
+own, padded = tiles.local_slots(w, h, rank, world)
+img, _ = s.render(rs, fs, ob.path_config(3, 1, 1, tile_rank=rank, tile_world=world), spp, threads=2)
+gcx = (w + 7) // 8
+local = np.zeros((padded, 4), np.float32)
+def compact(x):
+    x &= 0x55555555; x = (x ^ (x >> 1)) & 0x33333333; x = (x ^ (x >> 2)) & 0x0f0f0f0f; x = (x ^ (x >> 4)) & 0x00ff00ff; x = (x ^ (x >> 8)) & 0xffff
+    return x
+for slot in range(own):
+    g = (slot >> 6) * world + rank; lid = slot & 63
+    x, y = (g % gcx) * 8 + compact(lid), (g // gcx) * 8 + compact(lid >> 1)
+    if x < w and y < h:
+        local[slot] = img[y, x]
+gathered = tiles.gather_accumulators(torch.from_numpy(local), dst=0)
+if rank == 0:
+    assert gathered.shape == (world, padded, 4)
+    out = np.zeros((h, w, 4), np.float32)
+    own_map = tiles.tile_owner(w, h, world)
+    for y in range(h):
+        for x in range(w):
+            g = (y // 8) * gcx + (x // 8)
+            r, lg = g % world, g // world
+            lid = 0
+            for b in range(3):
+                lid |= (((x % 8) >> b) & 1) << (2 * b) | (((y % 8) >> b) & 1) << (2 * b + 1)
+            assert own_map[y, x] == r
+            out[y, x] = gathered[r, lg * 64 + lid].numpy()
+    whole, _ = s.render(rs, fs, ob.path_config(3, 1, 1), spp, threads=2)
+    assert np.array_equal(out.view(np.uint32), whole.view(np.uint32)), "gathered tiles differ from the single-rank image"
+    print("GLOO_TILES_OK")
+else:
+    assert gathered is None
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_tile_gather_over_gloo(tmp_path):
+    """world_size 2 on CPU: each rank renders its own tiles (oracle), tiles.gather_accumulators moves them to rank 0,
+    and the de-interleaved image equals the single-rank image bit for bit."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29613", str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "GLOO_TILES_OK" in r.stdout
