@@ -285,92 +285,21 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 #endif
 #define PT_NO_RAY 0xFFFFFFFFu
 
-// entry of the leaf child stored at node index `node` with triangles [first, first+count)
+// Entry of the leaf child stored at node index `node` with triangles [first, first+count).
+// Branch-free: both encodings are formed and one is selected.
 __device__ __forceinline__ uint32_t packLeaf(int32_t first, int32_t count, int32_t node) {
-    if (count <= PT_LEAF_MAX_COUNT && (uint32_t)first < PT_LEAF_MAX_FIRST) return PT_LEAF_FLAG | ((uint32_t)(count - 1) << 27) | (uint32_t)first;
-    return PT_LEAF_FLAG | (15u << 27) | (uint32_t)node;
+    const bool big = count > PT_LEAF_MAX_COUNT || (uint32_t)first >= PT_LEAF_MAX_FIRST;
+    const uint32_t small = ((uint32_t)(count - 1) << 27) | (uint32_t)first;
+    const uint32_t large = (15u << 27) | (uint32_t)node;
+    return PT_LEAF_FLAG | (big ? large : small);
 }
-
-enum { PT_MODE_INTERIOR = 0, PT_MODE_LEAF = 1, PT_MODE_DONE = 2 };
-
-// stack and entry handling, written as macros over the locals of traverseWave so that every
-// piece of per-ray state stays in registers
-#define PT_PUSH(e, t)                                                                \
-    do {                                                                             \
-        if (sp < PT_STACK_LDS) { lstack[sp * PT_WAVE + lane] = make_uint2((e), __float_as_uint(t)); sp++; } \
-        else if (sp < PT_STACK_TOTAL) { spill[sp - PT_STACK_LDS] = (e); spillT[sp - PT_STACK_LDS] = (t); sp++; } \
-        else (*overflow)++; /* the subtree is dropped; counted, never silent */      \
-    } while (0)
-#define PT_ENTER(e)                                                                  \
-    do {                                                                             \
-        const uint32_t e_ = (e);                                                     \
-        if (e_ & PT_LEAF_FLAG) {                                                     \
-            const uint32_t low_ = e_ & (PT_LEAF_MAX_FIRST - 1u), cm1_ = (e_ >> 27) & 15u; \
-            if (cm1_ < 15u) { leafJ = (int32_t)low_; leafEnd = leafJ + (int32_t)cm1_ + 1; } \
-            else { /* big leaf: node `low_` is half of pair record (low_-1)/2 */     \
-                const float4 rec_ = sc.pairs[2 * (size_t)(low_ - 1u) + 1];           \
-                leafJ = __float_as_int(rec_.z);                                      \
-                leafEnd = leafJ + __float_as_int(rec_.w);                            \
-            }                                                                        \
-            mode = PT_MODE_LEAF;                                                     \
-        } else {                                                                     \
-            curNode = (int32_t)e_;                                                   \
-            mode = PT_MODE_INTERIOR;                                                 \
-        }                                                                            \
-    } while (0)
-// pops until an entry whose entry distance is not beyond the best hit turns up (closest hit only:
-// an any-hit limit never shrinks, so everything pushed stays eligible)
-#define PT_POP_OR_END()                                                              \
-    do {                                                                             \
-        mode = PT_MODE_DONE;                                                         \
-        while (sp > 0) {                                                             \
-            sp--;                                                                    \
-            uint32_t top_;                                                           \
-            float topT_;                                                             \
-            if (sp < PT_STACK_LDS) { const uint2 r_ = lstack[sp * PT_WAVE + lane]; top_ = r_.x; topT_ = __uint_as_float(r_.y); } \
-            else { top_ = spill[sp - PT_STACK_LDS]; topT_ = spillT[sp - PT_STACK_LDS]; } \
-            if (ANYHIT || !(topT_ > best)) { PT_ENTER(top_); break; }                \
-        }                                                                            \
-    } while (0)
-#define PT_TEST_TRIANGLE(j_)                                                         \
-    do {                                                                             \
-        const int32_t tj_ = (j_);                                                    \
-        const float4* tp_ = sc.tri_hot + 3 * (size_t)tj_;                            \
-        const float4 q0_ = tp_[0], q1_ = tp_[1], q2_ = tp_[2];                       \
-        if (STATS) (*ntris)++;                                                       \
-        float tt_, tu_, tv_;                                                         \
-        if (triangleTest(q0_, q1_, q2_, o, d, &tt_, &tu_, &tv_)) {                   \
-            if (ANYHIT) { if (tt_ < tlimit) occluded = true; }                       \
-            else if (tt_ < best || (tt_ == best && tj_ < bestTri)) { best = tt_; bestTri = tj_; bu = tu_; bv = tv_; } \
-        }                                                                            \
-    } while (0)
-
-// one interior step of the lanes selected by `active`
-#define PT_INTERIOR_STEP(NANSAFE_)                                                                   \
-    do {                                                                                             \
-        if (STATS) (*nsteps)++;                                                                      \
-        const float4* p_ = sc.pairs + 2 * (size_t)(curNode - 1); /* pair (curNode-1)/2 */            \
-        const float4 a_ = p_[0], b_ = p_[1], c_ = p_[2], e_ = p_[3];                                 \
-        float lt_, rt_;                                                                              \
-        bool lhit_ = slabTest<NANSAFE_>(a_.x, a_.y, a_.z, a_.w, b_.x, b_.y, o, inv, &lt_);           \
-        bool rhit_ = slabTest<NANSAFE_>(c_.x, c_.y, c_.z, c_.w, e_.x, e_.y, o, inv, &rt_);           \
-        if (ANYHIT) { lhit_ = lhit_ && lt_ < tlimit; rhit_ = rhit_ && rt_ < tlimit; }                \
-        else { lhit_ = lhit_ && !(lt_ > best); rhit_ = rhit_ && !(rt_ > best); }                     \
-        const int32_t lfirst_ = __float_as_int(b_.z), lcount_ = __float_as_int(b_.w);                \
-        const int32_t rfirst_ = __float_as_int(e_.z), rcount_ = __float_as_int(e_.w);                \
-        const uint32_t eL_ = lcount_ > 0 ? packLeaf(lfirst_, lcount_, curNode) : (uint32_t)lfirst_;  \
-        const uint32_t eR_ = rcount_ > 0 ? packLeaf(rfirst_, rcount_, curNode + 1) : (uint32_t)rfirst_; \
-        if (lhit_ && rhit_) {                                                                        \
-            if (rt_ < lt_) { PT_PUSH(eL_, lt_); PT_ENTER(eR_); }                                     \
-            else { PT_PUSH(eR_, rt_); PT_ENTER(eL_); }                                               \
-        } else if (lhit_) PT_ENTER(eL_);                                                             \
-        else if (rhit_) PT_ENTER(eR_);                                                               \
-        else PT_POP_OR_END();                                                                        \
-    } while (0)
 
 // Source: struct with
 //   void load(uint32_t i, f3* o, f3* d, float* tlimit) const   — ray i of the queue
 //   void store(uint32_t i, const HitRec& h, bool occluded) const
+//
+// Lane state: `cur` is the current entry: 0 = no work (ray ended or lane idle), sign bit clear = interior
+// reference, sign bit set = leaf whose remaining triangles are [leafJ, leafEnd).
 template <bool ANYHIT, bool STATS, class Source>
 __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, const Source& src,
                                              uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched) {
@@ -390,22 +319,50 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
     float best = PT_INF, bu = 0.0f, bv = 0.0f, tlimit = PT_INF;
     int32_t bestTri = -1;
     bool occluded = false, special = false;
-    int mode = PT_MODE_DONE;
-    int32_t curNode = 0, leafJ = 0, leafEnd = 0;
+    uint32_t cur = 0;
+    int32_t leafJ = 0, leafEnd = 0;
     int sp = 0;
     uint32_t spill[PT_STACK_SPILL];
     float spillT[PT_STACK_SPILL];
+    uint2* const mystack = lstack + lane;
+
+    // makes `e` current; for a leaf also sets [leafJ, leafEnd)
+    auto enter = [&](uint32_t e) {
+        cur = e;
+        const uint32_t low = e & (PT_LEAF_MAX_FIRST - 1u), cm1 = (e >> 27) & 15u;
+        leafJ = (int32_t)low;
+        leafEnd = (int32_t)(low + cm1 + 1u);
+        if ((e >> 27) == 31u) {   // leaf too big to pack: `low` is its node index, half of pair record (low-1)/2
+            const float4 rec = sc.pairs[2 * (size_t)(low - 1u) + 1];
+            leafJ = __float_as_int(rec.z);
+            leafEnd = leafJ + __float_as_int(rec.w);
+        }
+    };
+    // pops until an entry whose entry distance is not beyond the best hit turns up (closest hit only:
+    // an any-hit limit never shrinks, so everything pushed stays eligible); 0 when the stack runs out
+    auto popNext = [&]() {
+        uint32_t next = 0;
+        while (sp > 0) {
+            sp--;
+            uint32_t e;
+            float t;
+            if (sp < PT_STACK_LDS) { const uint2 r = mystack[sp * PT_WAVE]; e = r.x; t = __uint_as_float(r.y); }
+            else { e = spill[sp - PT_STACK_LDS]; t = spillT[sp - PT_STACK_LDS]; }
+            if (ANYHIT || !(t > best)) { next = e; break; }
+        }
+        enter(next);
+    };
 
     for (;;) {
-        const unsigned long long interiorMask = __ballot(mode == PT_MODE_INTERIOR);
-        const unsigned long long leafMask = __ballot(mode == PT_MODE_LEAF);
+        const unsigned long long interiorMask = __ballot((int32_t)cur > 0);
+        const unsigned long long leafMask = __ballot((int32_t)cur < 0);
         const uint32_t nActive = (uint32_t)__popcll(interiorMask | leafMask);
-        const bool anyFinished = __ballot(rayIdx != PT_NO_RAY && mode == PT_MODE_DONE) != 0ull;
+        const bool anyFinished = __ballot(rayIdx != PT_NO_RAY && cur == 0u) != 0ull;
         const bool moreRays = !(exhausted && rangeLo == rangeHi);
         if (nActive == 0u || (64u - nActive >= PT_REFILL_MIN && (anyFinished || moreRays))) {
             // ---- retire finished rays, hand the idle lanes the next rays
             if (STATS) sched[2]++;
-            if (rayIdx != PT_NO_RAY && mode == PT_MODE_DONE) {
+            if (rayIdx != PT_NO_RAY && cur == 0u) {
                 HitRec h;
                 h.t = best; h.tri = bestTri; h.u = bu; h.v = bv;
                 src.store(rayIdx, h, occluded);
@@ -440,9 +397,11 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                 // the root test is done once per ray: always the NaN-propagating form
                 const bool in = sc.n_nodes > 0 &&
                                 slabTest<true>(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], o, inv, &tr);
-                if (!in) mode = PT_MODE_DONE;
-                else if (sc.root_count > 0) { leafJ = sc.root_left; leafEnd = sc.root_left + sc.root_count; mode = PT_MODE_LEAF; }
-                else { curNode = sc.root_left; mode = PT_MODE_INTERIOR; }
+                cur = 0;
+                if (in) {
+                    if (sc.root_count > 0) { cur = PT_LEAF_FLAG; leafJ = sc.root_left; leafEnd = sc.root_left + sc.root_count; }
+                    else cur = (uint32_t)sc.root_left;
+                }
             }
             const uint32_t nIdle = (uint32_t)__popcll(idleMask);
             rangeLo += nIdle < avail ? nIdle : avail;
@@ -451,17 +410,53 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
         // ---- one kind of work for the whole wave
         if (interiorMask != 0ull && (uint32_t)__popcll(leafMask) < PT_LEAF_BATCH) {
             if (STATS) sched[0]++;
-            if (__any(mode == PT_MODE_INTERIOR && special)) {
-                if (mode == PT_MODE_INTERIOR) PT_INTERIOR_STEP(true);
-            } else {
-                if (mode == PT_MODE_INTERIOR) PT_INTERIOR_STEP(false);
+            const bool nanSafe = __any((int32_t)cur > 0 && special);
+            if ((int32_t)cur > 0) {
+                if (STATS) (*nsteps)++;
+                const int32_t node = (int32_t)cur;
+                const float4* p = sc.pairs + 2 * (size_t)(node - 1);   // pair (node-1)/2, 4 float4 each
+                const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+                float lt, rt;
+                bool lhit, rhit;
+                if (nanSafe) {
+                    lhit = slabTest<true>(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, &lt);
+                    rhit = slabTest<true>(c.x, c.y, c.z, c.w, e.x, e.y, o, inv, &rt);
+                } else {
+                    lhit = slabTest<false>(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, &lt);
+                    rhit = slabTest<false>(c.x, c.y, c.z, c.w, e.x, e.y, o, inv, &rt);
+                }
+                if (ANYHIT) { lhit = lhit && lt < tlimit; rhit = rhit && rt < tlimit; }
+                else { lhit = lhit && !(lt > best); rhit = rhit && !(rt > best); }
+                const int32_t lfirst = __float_as_int(b.z), lcount = __float_as_int(b.w);
+                const int32_t rfirst = __float_as_int(e.z), rcount = __float_as_int(e.w);
+                const uint32_t eL = lcount > 0 ? packLeaf(lfirst, lcount, node) : (uint32_t)lfirst;
+                const uint32_t eR = rcount > 0 ? packLeaf(rfirst, rcount, node + 1) : (uint32_t)rfirst;
+                // nearer surviving child next, the other pushed with its entry distance
+                const bool rightFirst = rhit && (!lhit || rt < lt);
+                const uint32_t nearE = rightFirst ? eR : eL, farE = rightFirst ? eL : eR;
+                const float farT = rightFirst ? lt : rt;
+                if (lhit && rhit) {
+                    if (sp < PT_STACK_LDS) { mystack[sp * PT_WAVE] = make_uint2(farE, __float_as_uint(farT)); sp++; }
+                    else if (sp < PT_STACK_TOTAL) { spill[sp - PT_STACK_LDS] = farE; spillT[sp - PT_STACK_LDS] = farT; sp++; }
+                    else (*overflow)++;   // the subtree is dropped; counted, never silent
+                }
+                if (lhit || rhit) enter(nearE);
+                else popNext();
             }
         } else {
             if (STATS) sched[1]++;
-            if (mode == PT_MODE_LEAF) {
-                PT_TEST_TRIANGLE(leafJ);
-                if (ANYHIT && occluded) mode = PT_MODE_DONE;
-                else if (++leafJ == leafEnd) PT_POP_OR_END();
+            if ((int32_t)cur < 0) {
+                const int32_t j = leafJ;
+                const float4* tp = sc.tri_hot + 3 * (size_t)j;
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                if (STATS) (*ntris)++;
+                float tt, tu, tv;
+                if (triangleTest(q0, q1, q2, o, d, &tt, &tu, &tv)) {
+                    if (ANYHIT) { if (tt < tlimit) occluded = true; }
+                    else if (tt < best || (tt == best && j < bestTri)) { best = tt; bestTri = j; bu = tu; bv = tv; }
+                }
+                if (ANYHIT && occluded) cur = 0;
+                else if (++leafJ == leafEnd) popNext();
             }
         }
     }
