@@ -29,14 +29,25 @@ WORKLOADS = {
     # name: (description, width, height, spp, bounces, nee)
     "bundled": ("bundled scene (Game.InitializeScene(11), 165,208 triangles), 1920x1080, 16 spp, 4 bounces, NEE", 1920, 1080, 16, 4, 1),
     "soup1m": ("synthetic 1M-triangle random soup + SAH BVH, 1920x1080, 8 spp, 4 bounces, diffuse only, NEE", 1920, 1080, 8, 4, 1),
+    # the other BASELINE.json configs (parity/measurement cases, not the default bench line)
+    "c1": ("bundled scene, 512x512, 1 spp, primary + 1 bounce, no NEE (the reference's own setting)", 512, 512, 1, 2, 0),
+    "c3": ("synthetic 1M-triangle random soup + SAH BVH, 1920x1080, 64 spp, 4 bounces, diffuse only, NEE", 1920, 1080, 64, 4, 1),
+    "c4": ("bundled recipe + 19 bunnies (259,600 triangles, Sponza-scale), 3840x2160, 256 spp in steps of 32, 4 bounces, NEE", 3840, 2160, 32, 4, 1),
+    "c5": ("4,026 instanced bunnies flattened (20.0M triangles), 3840x2160, 1024 spp in steps of 8, 8 bounces, NEE", 3840, 2160, 8, 8, 1),
 }
 
 
 def build_scene(name, threads):
     from pathtracer_amd.host import Scene
-    if name == "bundled":
+    if name in ("bundled", "c1"):
         s = Scene()
         s.initialize_scene(11)
+    elif name == "c4":
+        s = Scene()
+        s.initialize_scene_extended(11, 19)
+    elif name == "c5":
+        s = Scene()
+        s.generate_instances(4026, 11)
     else:
         s = Scene("")
         s.generate_soup(1000000)
@@ -46,16 +57,18 @@ def build_scene(name, threads):
 
 def camera_for(name, w, h, wf):
     from pathtracer_amd.host import Camera
-    if name == "bundled":
+    if name in ("bundled", "c1", "c4"):
         # Game.Initialize sets the camera before the scene exists: focal distance stays 20 (Game.cs:45-51)
         return Camera(w, h, None), (0, 2, 15), (0, 3, 0)
+    if name == "c5":
+        return Camera(w, h, None), (0, 25, 70), (0, 18, 0)
     return Camera(w, h, None), (0, 0, 120), (0, 0, 0)
 
 
 def cpu_baseline(name, w, h, bounces, nee, fs, threads):
     """The oracle's literal restatement of the C# CPU traversal + shading on a bounded sample of the workload."""
     from oracle import binding as ob
-    if name == "bundled":
+    if name in ("bundled", "c1"):
         o = ob.Scene(os.path.join(ROOT, "pathtracer_amd", "assets", "meshes.bin"))
         o.initialize_scene(11)
     else:
@@ -93,6 +106,8 @@ def main():
     ap.add_argument("--bounces", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0, help="samples traced concurrently (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only for rehearsing N > 1 on a single GPU")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,10 +123,15 @@ def main():
     import pathtracer_amd as pa
     from pathtracer_amd import tiles
 
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     desc, w, h, spp, bounces, nee = WORKLOADS[args.workload]
     w, h = args.width or w, args.height or h
@@ -165,8 +185,9 @@ def main():
     dt = time.perf_counter() - t0
 
     st = wf.stats()
-    tot = torch.tensor([float(st["extend_rays"]), float(st["shadow_rays"]), dt], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
+    tot = torch.tensor([float(st["extend_rays"]), float(st["shadow_rays"]), dt], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -205,7 +226,7 @@ def main():
                          "extend_mrays_per_s": st["extend_rays"] / max(1e-9, st["ms_extend"] * 1e-3) / 1e6},
             "stage_ms_per_step": {k: st["ms_" + k] / args.steps for k in ("generate", "extend", "shade", "connect")},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("bundled", "c1", "soup1m", "c3"):
             fs0 = cam.frame_state(pos, tgt, frames=1, samples=0)
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(args.workload, w, h, bounces, nee, fs0, threads)

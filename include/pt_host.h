@@ -44,6 +44,14 @@ int pth_scene_add_triangles(pth_scene* s, const void* triangles112, int32_t n);
 /* Game.InitializeScene(seed), PathTracer/Game.cs:66-136: light + tiled floor + 60 random meshes */
 int pth_scene_initialize(pth_scene* s, int32_t seed);
 
+/* The bundled recipe followed by `extra_bunnies` more objects, all bunnies, drawn from the same random stream
+ * (19 extra = 259,600 triangles, the Sponza-scale synthetic input).  No reference counterpart. */
+int pth_scene_initialize_extended(pth_scene* s, int32_t seed, int32_t extra_bunnies);
+
+/* `count` randomly rotated bunnies on a cubic grid, flattened to triangles (4,026 = 20.0M triangles), plus the light.
+ * No reference counterpart. */
+int pth_scene_generate_instances(pth_scene* s, int32_t count, int32_t seed);
+
 /* Synthetic random triangle soup (no reference counterpart): n triangles in [-50,50]^3 with one emissive quad. */
 int pth_scene_generate_soup(pth_scene* s, int32_t n_triangles, uint32_t seed);
 

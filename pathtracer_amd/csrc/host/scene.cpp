@@ -377,7 +377,8 @@ struct pth_scene {
     }
 
     // Game.InitializeScene, Game.cs:66-136
-    void bundledScene(int seed) {
+    // `extra` further objects, all bunnies, continue the same random stream (a ~260k-triangle variant)
+    void bundledScene(int seed, int extra = 0) {
         Material tile;
         std::memset(&tile, 0, sizeof(tile));
         tile.Color[0] = 0.7f; tile.Color[1] = 0.7f; tile.Color[2] = 0.9f;
@@ -390,7 +391,7 @@ struct pth_scene {
         NetRandom rng(seed);
         const float pi = 3.14159274f;
         static const char* const shapes[5] = {"cube", "cube", "sphere", "sphere", "bunny"};
-        for (int i = 0; i < 60; i++) {
+        for (int i = 0; i < 60 + extra; i++) {
             Material m;
             std::memset(&m, 0, sizeof(m));
             for (int k = 0; k < 3; k++) m.Color[k] = (float)rng.nextDouble();
@@ -410,7 +411,38 @@ struct pth_scene {
             t = mul(t, rotationZ(rc));
             t = mul(t, translation(x, y, z));
             t = mul(t, uniformScale(s));
-            addMesh(shapes[rng.next(5)], true, t, &m);
+            const char* shape = shapes[rng.next(5)];
+            addMesh(i < 60 ? shape : "bunny", true, t, &m);
+        }
+    }
+
+    // Synthetic many-instance scene (no reference counterpart; the reference has no instancing, so
+    // instances are flattened): `count` bunnies on a cubic grid of pitch 2.5 with random rotations,
+    // scales in [0.8, 1.8) and materials drawn like the bundled recipe's, plus the light and a floor.
+    void instancedBunnies(int count, int seed) {
+        addMesh("light", false, identity(), nullptr);
+        NetRandom rng(seed);
+        const float pi = 3.14159274f;
+        int side = 1;
+        while (side * side * side < count) side++;
+        for (int i = 0; i < count; i++) {
+            Material m;
+            std::memset(&m, 0, sizeof(m));
+            for (int k = 0; k < 3; k++) m.Color[k] = (float)rng.nextDouble();
+            if (rng.next(100) > 97)
+                for (int k = 0; k < 3; k++) m.Emissive[k] = (float)rng.nextDouble() * 8.0f;
+            m.Index = 1.4f;
+            m.Type = rng.next(4);
+            m.Roughness = (float)rng.nextDouble();
+            const int gx = i % side, gy = (i / side) % side, gz = i / (side * side);
+            const float ra = (float)rng.nextDouble() * pi, rb = (float)rng.nextDouble() * pi, rc = (float)rng.nextDouble() * pi;
+            const float s = (float)rng.nextDouble() + 0.8f;
+            Mat4 t = uniformScale(s);
+            t = mul(t, rotationX(ra));
+            t = mul(t, rotationY(rb));
+            t = mul(t, rotationZ(rc));
+            t = mul(t, translation((gx - 0.5f * side) * 2.5f, gy * 2.5f + 0.5f, (gz - 0.5f * side) * 2.5f));
+            addMesh("bunny", true, t, &m);
         }
     }
 
@@ -475,6 +507,14 @@ int pth_scene_add_triangles(pth_scene* s, const void* triangles112, int32_t n) {
 }
 
 int pth_scene_initialize(pth_scene* s, int32_t seed) { PTH_GUARD(s->bundledScene(seed)) }
+
+int pth_scene_initialize_extended(pth_scene* s, int32_t seed, int32_t extra_bunnies) {
+    PTH_GUARD(if (extra_bunnies < 0) throw std::runtime_error("extra_bunnies < 0"); s->bundledScene(seed, extra_bunnies))
+}
+
+int pth_scene_generate_instances(pth_scene* s, int32_t count, int32_t seed) {
+    PTH_GUARD(if (count < 1) throw std::runtime_error("count < 1"); s->instancedBunnies(count, seed))
+}
 
 int pth_scene_generate_soup(pth_scene* s, int32_t n, uint32_t seed) { PTH_GUARD(if (n < 2) throw std::runtime_error("soup needs at least 2 triangles"); s->soup(n, seed)) }
 

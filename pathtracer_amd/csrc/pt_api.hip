@@ -102,7 +102,9 @@ uint32_t chooseBatch(const pt_ctx* c, uint32_t spp) {
         want = std::max(1u, target / std::max(1u, c->slots));
         want = std::min(want, 64u);
     }
-    return std::max(1u, std::min(want, std::max(1u, spp)));
+    // queue indices are 32-bit: never more than 2^30 paths in flight
+    const uint32_t cap = std::max(1u, (1u << 30) / std::max(1u, c->slots));
+    return std::max(1u, std::min(std::min(want, cap), std::max(1u, spp)));
 }
 
 hipEvent_t getEvent(pt_ctx* c) {

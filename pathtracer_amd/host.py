@@ -36,6 +36,8 @@ def _lib():
         lib.pth_scene_add_triangles.argtypes = [vp, vp, i32]
         lib.pth_scene_initialize.argtypes = [vp, i32]
         lib.pth_scene_generate_soup.argtypes = [vp, i32, C.c_uint32]
+        lib.pth_scene_initialize_extended.argtypes = [vp, i32, i32]
+        lib.pth_scene_generate_instances.argtypes = [vp, i32, i32]
         lib.pth_scene_build.argtypes = [vp, i32]
         lib.pth_scene_counts.argtypes = [vp, vp]
         lib.pth_scene_arrays.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -88,6 +90,12 @@ class Scene:
 
     def initialize_scene(self, seed=11):
         _chk(self._lib.pth_scene_initialize(self._h, seed))
+
+    def initialize_scene_extended(self, seed=11, extra_bunnies=19):
+        _chk(self._lib.pth_scene_initialize_extended(self._h, seed, extra_bunnies))
+
+    def generate_instances(self, count, seed=11):
+        _chk(self._lib.pth_scene_generate_instances(self._h, count, seed))
 
     def generate_soup(self, n_triangles, seed=0x9E3779B9):
         _chk(self._lib.pth_scene_generate_soup(self._h, n_triangles, C.c_uint32(seed)))

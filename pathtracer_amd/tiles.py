@@ -38,8 +38,9 @@ def accumulator_tensor(wf):
 def gather_accumulators(local, dst=0, group=None):
     """Gather every rank's accumulator tensor to `dst`.  Returns (world, n, 4) there, None elsewhere.
 
-    Works on any backend: with "nccl" the tensors stay on the GPU and move over xGMI via RCCL;
-    with "gloo" they are CPU tensors (used by the CPU tests of the multi-rank path).
+    With the "nccl" backend the tensors stay on the GPU and move over xGMI via RCCL.  Other backends
+    (gloo: the CPU tests and single-GPU rehearsals of the multi-rank path) carry CPU copies; the result
+    comes back on the device `local` lives on.
     """
     import torch
     import torch.distributed as dist
@@ -47,11 +48,15 @@ def gather_accumulators(local, dst=0, group=None):
     rank = dist.get_rank(group)
     if world == 1:
         return local.unsqueeze(0)
+    device = local.device
+    staged = local
+    if dist.get_backend(group) != "nccl" and local.is_cuda:
+        staged = local.cpu()
     if rank == dst:
-        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-        dist.gather(local, list(out.unbind(0)), dst=dst, group=group)
-        return out
-    dist.gather(local, None, dst=dst, group=group)
+        out = torch.empty((world,) + tuple(staged.shape), dtype=staged.dtype, device=staged.device)
+        dist.gather(staged, list(out.unbind(0)), dst=dst, group=group)
+        return out.to(device)
+    dist.gather(staged, None, dst=dst, group=group)
     return None
 
 

@@ -327,3 +327,54 @@ def test_tile_sharding_single_process(pa, ob, bundled):
     assert np.array_equal(bits(got), bits(want))
     for c in ctxs:
         c.close()
+
+
+RANK_WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+import pathtracer_amd as pa
+from pathtracer_amd import tiles
+from pathtracer_amd.host import Scene, Camera
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+w, h, spp = 200, 120, 3
+s = Scene(); s.initialize_scene(11); s.build(2)
+fs = Camera(w, h).frame_state((0, 2, 15), (0, 3, 0), frames=1, samples=0)
+wf = pa.Wavefront(device=0, nee=True, rng_mode=1, tile_rank=rank, tile_world=world)
+wf.upload_scene(*s.arrays())
+wf.allocate(w, h)
+wf.invoke(fs, spp=spp, max_bounces=4)
+img = tiles.gather_image(wf, spp, dst=0)
+if rank == 0:
+    ref = pa.Wavefront(device=0, nee=True, rng_mode=1)
+    ref.upload_scene(*s.arrays())
+    ref.allocate(w, h)
+    ref.invoke(fs, spp=spp, max_bounces=4)
+    want = ref.read_image()
+    assert np.array_equal(img.view(np.uint32), want.view(np.uint32)), "tile-sharded image differs from the single-context image"
+    print("RANKS_OK")
+else:
+    assert img is None
+dist.barrier()
+wf.close()
+dist.destroy_process_group()
+"""
+
+
+def test_two_processes_share_one_gpu(tmp_path):
+    """One process per rank (as bench.py --gpus N runs), both on cuda:0, gathered over gloo: the assembled image
+    equals the single-context image bit for bit."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "rank_worker.py"
+    script.write_text(RANK_WORKER.format(root=ROOT))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29617", str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "RANKS_OK" in r.stdout
