@@ -35,7 +35,7 @@ class pt_stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
-PT_OPT_NEE, PT_OPT_RNG_MODE, PT_OPT_TRAVERSAL_STATS, PT_OPT_STAGE_TIMING, PT_OPT_SAMPLES_PER_BATCH = 1, 2, 3, 4, 5
+PT_OPT_NEE, PT_OPT_RNG_MODE, PT_OPT_TRAVERSAL_STATS, PT_OPT_STAGE_TIMING, PT_OPT_SAMPLES_PER_BATCH, PT_OPT_TRAVERSE_BLOCKS_PER_CU = 1, 2, 3, 4, 5, 6
 
 # every symbol include/pt_hip.h declares
 PT_HIP_SYMBOLS = ["pt_default_config", "pt_create", "pt_destroy", "pt_last_error", "pt_upload_scene", "pt_resize",

@@ -55,7 +55,7 @@ struct pt_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool render_pending = false;
     pt_stats host_stats{};
-    int grid_extend = 0, grid_connect = 0, grid_shade = 0;
+    int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
 };
 
 #define FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); if (ctx) (ctx)->err = _b; else g_err = _b; return (code); } while (0)
@@ -209,8 +209,10 @@ int pt_create(const pt_config* cfg, pt_ctx** out) {
     c->num_cu = prop.multiProcessorCount;
     int perCu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_extend<false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    c->fit_extend = perCu;
     c->grid_extend = c->num_cu * perCu;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_connect<false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    c->fit_connect = perCu;
     c->grid_connect = c->num_cu * perCu;
     c->grid_shade = c->num_cu * 4;
     *out = c;
@@ -240,6 +242,11 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
         case PT_OPT_RNG_MODE: if (value != 0 && value != 1) FAIL(c, PT_E_INVALID_ARG, "rng_mode %d", value); c->cfg.rng_mode = value; break;
         case PT_OPT_TRAVERSAL_STATS: c->cfg.traversal_stats = value ? 1 : 0; break;
         case PT_OPT_STAGE_TIMING: c->cfg.stage_timing = value ? 1 : 0; break;
+        case PT_OPT_TRAVERSE_BLOCKS_PER_CU:
+            if (value < 0 || value > 16) FAIL(c, PT_E_INVALID_ARG, "traverse blocks per CU %d", value);
+            c->grid_extend = c->num_cu * (value ? std::min(value, c->fit_extend) : c->fit_extend);
+            c->grid_connect = c->num_cu * (value ? std::min(value, c->fit_connect) : c->fit_connect);
+            break;
         case PT_OPT_SAMPLES_PER_BATCH: if (value < 0) FAIL(c, PT_E_INVALID_ARG, "samples_per_batch %d", value); c->cfg.samples_per_batch = value; break;
         default: FAIL(c, PT_E_INVALID_ARG, "unknown option %d", key);
     }

@@ -322,8 +322,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
     uint32_t cur = 0;
     int32_t leafJ = 0, leafEnd = 0;
     int sp = 0;
-    uint32_t spill[PT_STACK_SPILL];
-    float spillT[PT_STACK_SPILL];
+    uint2 spill[PT_STACK_SPILL];
     uint2* const mystack = lstack + lane;
 
     // makes `e` current; for a leaf also sets [leafJ, leafEnd)
@@ -344,71 +343,81 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
         uint32_t next = 0;
         while (sp > 0) {
             sp--;
-            uint32_t e;
-            float t;
-            if (sp < PT_STACK_LDS) { const uint2 r = mystack[sp * PT_WAVE]; e = r.x; t = __uint_as_float(r.y); }
-            else { e = spill[sp - PT_STACK_LDS]; t = spillT[sp - PT_STACK_LDS]; }
-            if (ANYHIT || !(t > best)) { next = e; break; }
+            const int slot = sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1;
+            uint2 r = mystack[slot * PT_WAVE];
+            // opaque to the optimiser: otherwise the LDS and scratch reads are merged into one flat access
+            asm volatile("" : "+v"(r.x), "+v"(r.y));
+            if (sp >= PT_STACK_LDS) r = spill[sp - PT_STACK_LDS];
+            if (ANYHIT || !(__uint_as_float(r.y) > best)) { next = r.x; break; }
         }
         enter(next);
     };
+    auto push = [&](uint32_t e, float t) {
+        const bool room = sp < PT_STACK_TOTAL;
+        const uint2 r = make_uint2(e, __float_as_uint(t));
+        if (sp < PT_STACK_LDS) mystack[sp * PT_WAVE] = r;
+        else if (room) spill[sp - PT_STACK_LDS] = r;
+        sp += room ? 1 : 0;
+        if (!room) *overflow += 1u;   // the subtree is dropped; counted, never silent
+    };
 
     for (;;) {
-        const unsigned long long interiorMask = __ballot((int32_t)cur > 0);
-        const unsigned long long leafMask = __ballot((int32_t)cur < 0);
-        const uint32_t nActive = (uint32_t)__popcll(interiorMask | leafMask);
-        const bool anyFinished = __ballot(rayIdx != PT_NO_RAY && cur == 0u) != 0ull;
-        const bool moreRays = !(exhausted && rangeLo == rangeHi);
-        if (nActive == 0u || (64u - nActive >= PT_REFILL_MIN && (anyFinished || moreRays))) {
-            // ---- retire finished rays, hand the idle lanes the next rays
-            if (STATS) sched[2]++;
-            if (rayIdx != PT_NO_RAY && cur == 0u) {
-                HitRec h;
-                h.t = best; h.tri = bestTri; h.u = bu; h.v = bv;
-                src.store(rayIdx, h, occluded);
-                rayIdx = PT_NO_RAY;
-            }
-            if (rangeLo == rangeHi && !exhausted) {
-                uint32_t got = 0;
-                if (lane == 0) got = atomicAdd(cursor, grab);
-                got = __shfl(got, 0);
-                const uint32_t lo = dynBase + got;
-                if (lo >= n) exhausted = true;
-                else { rangeLo = lo; rangeHi = lo + grab < n ? lo + grab : n; }
-            }
-            const uint32_t avail = rangeHi - rangeLo;
-            if (avail == 0u) {
-                if (nActive == 0u) break;   // nothing in flight and nothing left to hand out
-                continue;
-            }
-            const unsigned long long idleMask = __ballot(rayIdx == PT_NO_RAY);
-            const uint32_t rank = (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
-            if (rayIdx == PT_NO_RAY && rank < avail) {
-                rayIdx = rangeLo + rank;
-                src.load(rayIdx, &o, &d, &tlimit);
-                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // Ray.cs:18
-                best = tlimit;
-                bestTri = -1;
-                bu = bv = 0.0f;
-                occluded = false;
-                sp = 0;
-                special = raySpecial(o, d);
-                float tr;
-                // the root test is done once per ray: always the NaN-propagating form
-                const bool in = sc.n_nodes > 0 &&
-                                slabTest<true>(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], o, inv, &tr);
-                cur = 0;
-                if (in) {
-                    if (sc.root_count > 0) { cur = PT_LEAF_FLAG; leafJ = sc.root_left; leafEnd = sc.root_left + sc.root_count; }
-                    else cur = (uint32_t)sc.root_left;
+        // ---- retire finished rays and hand the idle lanes the next rays: when nothing is in flight, or when
+        //      PT_REFILL_MIN lanes are idle and rays remain to be handed out
+        {
+            const uint32_t nActive = (uint32_t)__popcll(__ballot(cur != 0u));
+            const bool moreRays = !(exhausted && rangeLo == rangeHi);
+            if (nActive == 0u || (moreRays && 64u - nActive >= PT_REFILL_MIN)) {
+                if (STATS) sched[2]++;
+                if (rayIdx != PT_NO_RAY && cur == 0u) {
+                    HitRec h;
+                    h.t = best; h.tri = bestTri; h.u = bu; h.v = bv;
+                    src.store(rayIdx, h, occluded);
+                    rayIdx = PT_NO_RAY;
                 }
+                if (rangeLo == rangeHi && !exhausted) {
+                    uint32_t got = 0;
+                    if (lane == 0) got = atomicAdd(cursor, grab);
+                    got = __shfl(got, 0);
+                    const uint32_t lo = dynBase + got;
+                    if (lo >= n) exhausted = true;
+                    else { rangeLo = lo; rangeHi = lo + grab < n ? lo + grab : n; }
+                }
+                const uint32_t avail = rangeHi - rangeLo;
+                if (avail == 0u && nActive == 0u) break;   // nothing in flight and nothing left to hand out
+                const unsigned long long idleMask = __ballot(rayIdx == PT_NO_RAY);
+                const uint32_t rank = (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
+                if (rayIdx == PT_NO_RAY && rank < avail) {
+                    rayIdx = rangeLo + rank;
+                    src.load(rayIdx, &o, &d, &tlimit);
+                    inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // Ray.cs:18
+                    best = tlimit;
+                    bestTri = -1;
+                    bu = bv = 0.0f;
+                    occluded = false;
+                    sp = 0;
+                    special = raySpecial(o, d);
+                    float tr;
+                    // the root test is done once per ray: always the NaN-propagating form
+                    const bool in = sc.n_nodes > 0 &&
+                                    slabTest<true>(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], o, inv, &tr);
+                    cur = 0;
+                    if (in) {
+                        if (sc.root_count > 0) { cur = PT_LEAF_FLAG; leafJ = sc.root_left; leafEnd = sc.root_left + sc.root_count; }
+                        else cur = (uint32_t)sc.root_left;
+                    }
+                }
+                const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+                rangeLo += nIdle < avail ? nIdle : avail;
             }
-            const uint32_t nIdle = (uint32_t)__popcll(idleMask);
-            rangeLo += nIdle < avail ? nIdle : avail;
-            continue;
         }
-        // ---- one kind of work for the whole wave
-        if (interiorMask != 0ull && (uint32_t)__popcll(leafMask) < PT_LEAF_BATCH) {
+        const bool refillable = !(exhausted && rangeLo == rangeHi);
+        // ---- interior steps, for as long as that is the wave's kind of work
+        for (;;) {
+            const unsigned long long interiorMask = __ballot((int32_t)cur > 0);
+            const uint32_t nLeaf = (uint32_t)__popcll(__ballot((int32_t)cur < 0));
+            if (interiorMask == 0ull || nLeaf >= PT_LEAF_BATCH) break;
+            if (refillable && 64u - (uint32_t)__popcll(interiorMask) - nLeaf >= PT_REFILL_MIN) break;
             if (STATS) sched[0]++;
             const bool nanSafe = __any((int32_t)cur > 0 && special);
             if ((int32_t)cur > 0) {
@@ -435,15 +444,19 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                 const bool rightFirst = rhit && (!lhit || rt < lt);
                 const uint32_t nearE = rightFirst ? eR : eL, farE = rightFirst ? eL : eR;
                 const float farT = rightFirst ? lt : rt;
-                if (lhit && rhit) {
-                    if (sp < PT_STACK_LDS) { mystack[sp * PT_WAVE] = make_uint2(farE, __float_as_uint(farT)); sp++; }
-                    else if (sp < PT_STACK_TOTAL) { spill[sp - PT_STACK_LDS] = farE; spillT[sp - PT_STACK_LDS] = farT; sp++; }
-                    else (*overflow)++;   // the subtree is dropped; counted, never silent
-                }
+                if (lhit && rhit) push(farE, farT);
                 if (lhit || rhit) enter(nearE);
                 else popNext();
             }
-        } else {
+        }
+        // ---- triangle tests, one per waiting lane and iteration
+        for (;;) {
+            const unsigned long long leafMask = __ballot((int32_t)cur < 0);
+            if (leafMask == 0ull) break;
+            const uint32_t nLeaf = (uint32_t)__popcll(leafMask);
+            const uint32_t nInterior = (uint32_t)__popcll(__ballot((int32_t)cur > 0));
+            if (nInterior != 0u && nLeaf < PT_LEAF_BATCH) break;
+            if (refillable && 64u - nInterior - nLeaf >= PT_REFILL_MIN) break;
             if (STATS) sched[1]++;
             if ((int32_t)cur < 0) {
                 const int32_t j = leafJ;

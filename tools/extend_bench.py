@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4000000)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--blocks", type=int, default=0, help="resident traversal blocks per CU (0 = as many as fit)")
     ap.add_argument("--coherent", action="store_true", help="primary camera rays instead of bounce rays")
     args = ap.parse_args()
 
@@ -46,6 +47,8 @@ def main():
     print(f"scene {args.scene}: {tris.size} triangles, {nodes.size} nodes, depth {s.counts()['depth']}, built in {time.time() - t0:.1f}s", flush=True)
 
     wf = pa.Wavefront(traversal_stats=args.stats)
+    if args.blocks:
+        wf.set_option(6, args.blocks)
     wf.upload_scene(mats, tris, nodes)
     rng = np.random.RandomState(1)
     n = args.rays
