@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--bounces", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0, help="samples traced concurrently (0 = automatic)")
+    ap.add_argument("--blocks", type=int, default=-1, help="resident traversal blocks per CU (-1 = the library's choice, 0 = as many as fit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only for rehearsing N > 1 on a single GPU")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
@@ -143,6 +144,8 @@ def main():
     wf = pa.Wavefront(device=local_rank, nee=bool(nee), rng_mode=1, tile_rank=rank, tile_world=world,
                       samples_per_batch=args.batch, stage_timing=True)
     wf.upload_scene(mats, tris, nodes)
+    if args.blocks >= 0:
+        wf.set_option(6, args.blocks)
     wf.allocate(w, h)
     cam, pos, tgt = camera_for(args.workload, w, h, wf)
     fs = cam.frame_state(pos, tgt, frames=1, samples=0)
@@ -196,8 +199,8 @@ def main():
 
     if rank == 0:
         # dominant kernel: extend.  Algorithmic bytes per ray = 32 (origin+direction in) + 16 (hit out)
-        # + 64 per BVH step (one sibling-pair record) + 48 per triangle test (one hot triangle record).
-        b_ray = 48.0 + 64.0 * steps_per_ray + 48.0 * tris_per_ray
+        # + 128 per BVH step (one quad record: four boxes and entries) + 48 per triangle test (one hot triangle record).
+        b_ray = 48.0 + 128.0 * steps_per_ray + 48.0 * tris_per_ray
         ext_launches = max(1, st["extend_launches"])
         avg_ms = st["ms_extend"] / ext_launches
         bytes_per_launch = b_ray * st["extend_rays"] / ext_launches

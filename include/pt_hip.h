@@ -131,7 +131,7 @@ int pt_reset_stats(pt_ctx* ctx);
 
 /* Runtime switches: key is one of PT_OPT_*; takes effect at the next pt_render. */
 enum { PT_OPT_NEE = 1, PT_OPT_RNG_MODE = 2, PT_OPT_TRAVERSAL_STATS = 3, PT_OPT_STAGE_TIMING = 4, PT_OPT_SAMPLES_PER_BATCH = 5,
-       PT_OPT_TRAVERSE_BLOCKS_PER_CU = 6 /* resident 256-thread blocks per CU of the traversal kernels; 0 = as many as fit */ };
+       PT_OPT_TRAVERSE_BLOCKS_PER_CU = 6 /* resident 256-thread blocks per CU of the traversal kernels; 0 = the default (at most 7) */ };
 int pt_set_option(pt_ctx* ctx, int32_t key, int32_t value);
 
 /* ---- multi-GPU tiles ---------------------------------------------------------

@@ -1,5 +1,6 @@
 // CPU ORACLE — TEST INFRASTRUCTURE ONLY (see oracle.hpp).
 // Restates PathTracer/Box.cs, Ray.cs, Triangle.cs and Accelerator.cs.
+#include <cstring>
 #include "oracle.hpp"
 #include <cmath>
 #include <limits>
@@ -158,7 +159,8 @@ void Accelerator::Intersect(const Ray& ray, Intersection& i) const {
     }
 }
 
-// Canonical closest hit: the minimum over all accepted Möller–Trumbore hits, ties broken by
+// Canonical closest hit (two-wide walk; see WalkWide for the one most rays take): the minimum over all accepted
+// Möller–Trumbore hits, ties broken by
 // the smallest triangle index.  The visiting order is the one the GPU kernels use, step for
 // step, so that distance culling (which compares box entry distances with triangle
 // distances, two differently rounded quantities) takes the same decisions on both sides:
@@ -248,8 +250,103 @@ static bool Walk(const Accelerator& acc, const Ray& ray, Intersection& i, bool a
     }
 }
 
+// A ray whose slab distances can be NaN (0 * inf): a zero, denormal or non-finite direction
+// component, or a non-finite origin.  Such rays take the two-wide walk above; all others the
+// wide walk below.
+static inline bool RaySpecial(const Ray& ray) {
+    const float d[3] = {ray.Direction.x, ray.Direction.y, ray.Direction.z};
+    const float o[3] = {ray.Origin.x, ray.Origin.y, ray.Origin.z};
+    for (int k = 0; k < 3; k++) {
+        if (!(std::fabs(d[k]) >= 1.0e-37f && std::fabs(d[k]) <= 3.0e38f)) return true;
+        if (!(std::fabs(o[k]) <= 3.0e38f)) return true;
+    }
+    return false;
+}
+
+// The wide walk: the same tree with every other level skipped.  An interior entry stands for an
+// interior node at an even depth; a step slab-tests its grandchildren (a child that is a leaf
+// stands for itself; slot order: the left child's expansion first), drops the culled ones as in
+// the two-wide walk, makes the nearest survivor current and pushes the others, farthest first.
+// The order key of a child is its entry distance clamped at zero with the two lowest mantissa bits
+// replaced by the slot number; pushed entries carry the key with those bits cleared as distance.
+static bool WalkWide(const Accelerator& acc, const Ray& ray, Intersection& i, bool anyHit, float tlimit, TraversalStats* st) {
+    const auto& nodes = acc.nodes;
+    const auto& triangles = acc.triangles;
+    if (st) st->rays++;
+    if (nodes.empty()) return false;
+    if (!BoxIntersect(nodes[0].Bounds, ray, nullptr, nullptr)) return false;
+    bool occluded = false;
+    auto testTriangle = [&](int j) {
+        if (st) st->tris++;
+        if (anyHit) {
+            Intersection probe;
+            probe.Distance = INF;
+            probe.Tri = -1;
+            if (TriangleIntersect(triangles[j], ray, probe, j) && probe.Distance < tlimit) occluded = true;
+        } else {
+            AcceptCanonical(triangles[j], ray, i, j);
+        }
+    };
+    std::vector<Entry> stack;
+    Entry cur = nodes[0].Count > 0 ? entryOf(nodes[0]) : Entry{false, 0, 0, 0, 0.0f};   // interior entries name the node itself here
+    auto pop = [&]() {
+        while (!stack.empty()) {
+            Entry e = stack.back();
+            stack.pop_back();
+            if (anyHit || !(e.tmin > i.Distance)) { cur = e; return true; }
+        }
+        return false;
+    };
+    for (;;) {
+        if (cur.leaf) {
+            for (int j = cur.first; j < cur.first + cur.count; j++) {
+                testTriangle(j);
+                if (occluded) return true;
+            }
+            if (!pop()) return false;
+            continue;
+        }
+        if (st) st->steps++;
+        int kids[4];
+        int nk = 0;
+        for (int ch = nodes[cur.node].LeftFirst; ch <= nodes[cur.node].LeftFirst + 1; ch++) {
+            if (nodes[ch].Count > 0) kids[nk++] = ch;
+            else { kids[nk++] = nodes[ch].LeftFirst; kids[nk++] = nodes[ch].LeftFirst + 1; }
+        }
+        uint32_t keys[4];
+        int who[4];
+        int nh = 0;
+        for (int k = 0; k < nk; k++) {
+            float tm;
+            bool h = BoxIntersect(nodes[kids[k]].Bounds, ray, &tm, nullptr);
+            h = h && (anyHit ? tm < tlimit : !(tm > i.Distance));
+            if (!h) continue;
+            const float tk = tm > 0.0f ? tm : 0.0f;
+            uint32_t bits;
+            std::memcpy(&bits, &tk, 4);
+            keys[nh] = (bits & ~3u) | (uint32_t)k;
+            who[nh] = kids[k];
+            nh++;
+        }
+        // ascending by key (keys are unique)
+        for (int a = 1; a < nh; a++)
+            for (int b = a; b > 0 && keys[b] < keys[b - 1]; b--) { std::swap(keys[b], keys[b - 1]); std::swap(who[b], who[b - 1]); }
+        auto entryFor = [&](int slot) {
+            const Node& n = nodes[who[slot]];
+            Entry e = n.Count > 0 ? entryOf(n) : Entry{false, 0, 0, who[slot], 0.0f};
+            const uint32_t bits = keys[slot] & ~3u;
+            std::memcpy(&e.tmin, &bits, 4);
+            return e;
+        };
+        for (int a = nh - 1; a >= 1; a--) stack.push_back(entryFor(a));
+        if (nh > 0) cur = entryFor(0);
+        else if (!pop()) return false;
+    }
+}
+
 void Accelerator::IntersectCanonical(const Ray& ray, Intersection& i, TraversalStats* st) const {
-    Walk(*this, ray, i, false, INF, st);
+    if (RaySpecial(ray)) Walk(*this, ray, i, false, INF, st);
+    else WalkWide(*this, ray, i, false, INF, st);
 }
 
 void Accelerator::IntersectBrute(const Ray& ray, Intersection& i) const {
@@ -262,7 +359,8 @@ bool Accelerator::Occluded(const Ray& ray, float tmax, TraversalStats* st) const
     Intersection unused;
     unused.Distance = INF;
     unused.Tri = -1;
-    return Walk(*this, ray, unused, true, tmax, st);
+    if (RaySpecial(ray)) return Walk(*this, ray, unused, true, tmax, st);
+    return WalkWide(*this, ray, unused, true, tmax, st);
 }
 
 int Accelerator::MaxDepth() const {

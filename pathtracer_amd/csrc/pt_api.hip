@@ -34,7 +34,7 @@ struct pt_ctx {
     int num_cu = 256;
     // scene
     DevScene sc{};
-    void *d_pairs = nullptr, *d_hot = nullptr, *d_cold = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+    void *d_pairs = nullptr, *d_quads = nullptr, *d_big = nullptr, *d_hot = nullptr, *d_cold = nullptr, *d_mats = nullptr, *d_lights = nullptr;
     bool has_scene = false;
     // image / queues
     int width = 0, height = 0;
@@ -55,7 +55,7 @@ struct pt_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool render_pending = false;
     pt_stats host_stats{};
-    int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
+    int grid_extend = 0, grid_connect = 0, grid_shade = 0, grid_special = 0, fit_extend = 1, fit_connect = 1;
 };
 
 #define FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); if (ctx) (ctx)->err = _b; else g_err = _b; return (code); } while (0)
@@ -74,7 +74,7 @@ void freeQueues(pt_ctx* c) {
 }
 
 void freeScene(pt_ctx* c) {
-    void** ps[] = {&c->d_pairs, &c->d_hot, &c->d_cold, &c->d_mats, &c->d_lights};
+    void** ps[] = {&c->d_pairs, &c->d_quads, &c->d_big, &c->d_hot, &c->d_cold, &c->d_mats, &c->d_lights};
     for (void** p : ps) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
     c->has_scene = false;
     c->sc = DevScene{};
@@ -89,6 +89,12 @@ int allocQueues(pt_ctx* c, uint32_t capacity) {
         HIPCHECK(c, hipMalloc(&p, (size_t)capacity * sizeof(float4)));
         c->qmem.push_back(p);
         *col = (float4*)p;
+    }
+    {
+        void* p = nullptr;
+        HIPCHECK(c, hipMalloc(&p, (size_t)capacity * sizeof(uint32_t)));
+        c->qmem.push_back(p);
+        c->q.special = (uint32_t*)p;
     }
     c->capacity = capacity;
     return PT_OK;
@@ -208,13 +214,16 @@ int pt_create(const pt_config* cfg, pt_ctx** out) {
     }
     c->num_cu = prop.multiProcessorCount;
     int perCu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_extend<false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_extend<false, false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
     c->fit_extend = perCu;
+    perCu = std::min(perCu, 7);   // more resident waves than this thrash the caches on incoherent rays
     c->grid_extend = c->num_cu * perCu;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_connect<false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_connect<false, false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
     c->fit_connect = perCu;
+    perCu = std::min(perCu, 7);
     c->grid_connect = c->num_cu * perCu;
     c->grid_shade = c->num_cu * 4;
+    c->grid_special = c->num_cu * 2;
     *out = c;
     return PT_OK;
 }
@@ -244,8 +253,8 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
         case PT_OPT_STAGE_TIMING: c->cfg.stage_timing = value ? 1 : 0; break;
         case PT_OPT_TRAVERSE_BLOCKS_PER_CU:
             if (value < 0 || value > 16) FAIL(c, PT_E_INVALID_ARG, "traverse blocks per CU %d", value);
-            c->grid_extend = c->num_cu * (value ? std::min(value, c->fit_extend) : c->fit_extend);
-            c->grid_connect = c->num_cu * (value ? std::min(value, c->fit_connect) : c->fit_connect);
+            c->grid_extend = c->num_cu * std::min(value ? value : 7, c->fit_extend);
+            c->grid_connect = c->num_cu * std::min(value ? value : 7, c->fit_connect);
             break;
         case PT_OPT_SAMPLES_PER_BATCH: if (value < 0) FAIL(c, PT_E_INVALID_ARG, "samples_per_batch %d", value); c->cfg.samples_per_batch = value; break;
         default: FAIL(c, PT_E_INVALID_ARG, "unknown option %d", key);
@@ -264,7 +273,8 @@ int pt_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void*
     int depth = 0;
     int rc = validateBvh(c, hn, n_nodes, n_tri, &depth);
     if (rc != PT_OK) return rc;
-    if (depth > PT_STACK_TOTAL) FAIL(c, PT_E_BAD_BVH, "BVH depth %d exceeds the traversal stack (%d)", depth, PT_STACK_TOTAL);
+    // the wide traversal pushes up to three entries on each of its (depth + 1) / 2 levels
+    if (depth > PT_STACK_TOTAL || 3 * ((depth + 1) / 2) > PT_STACK_TOTAL) FAIL(c, PT_E_BAD_BVH, "BVH depth %d exceeds the traversal stack (%d entries)", depth, PT_STACK_TOTAL);
     for (int i = 0; i < n_tri; i++)
         if (ht[i].material < 0 || ht[i].material >= n_mat) FAIL(c, PT_E_INVALID_ARG, "triangle %d has material %d of %d", i, ht[i].material, n_mat);
 
@@ -302,8 +312,56 @@ int pt_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void*
         HIPCHECK(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
         return PT_OK;
     };
-    // sibling pair k = nodes[2k+1], nodes[2k+2]: the node array shifted by one node lands on 64-byte lines
-    if ((rc = upload(&c->d_pairs, n_pairs ? hn + 1 : nullptr, (size_t)n_pairs * 64)) != PT_OK) return rc;
+    // sibling pair k = nodes[2k+1], nodes[2k+2]: the node array shifted by one node lands on 64-byte lines;
+    // each node's leftFirst word becomes its traversal entry
+    std::vector<HostNode> pairs(hn + (n_pairs ? 1 : 0), hn + (n_pairs ? 1 + 2 * (size_t)n_pairs : 0));
+    std::vector<uint2> big;
+    std::vector<uint32_t> leafEntry(pairs.size() + 1, 0u);   // by node index
+    for (size_t i = 0; i < pairs.size(); i++) {
+        HostNode& nd = pairs[i];
+        if (nd.count <= 0) continue;   // interior: the entry is the left child's index itself
+        const uint32_t e = packLeaf(nd.leftFirst, nd.count, (uint32_t)big.size());
+        if (!leafFitsPacked(nd.leftFirst, nd.count)) big.push_back(make_uint2((uint32_t)nd.leftFirst, (uint32_t)nd.count));
+        memcpy(&nd.leftFirst, &e, 4);
+        leafEntry[i + 1] = e;
+    }
+    if (big.size() >= PT_LEAF_MAX_FIRST) FAIL(c, PT_E_BAD_BVH, "%zu leaves of more than %d triangles", big.size(), PT_LEAF_MAX_COUNT);
+    // quad records: every other level of the tree, starting at the root
+    struct Quad { float box[6][4]; uint32_t entry[4]; uint32_t pad[4]; };
+    static_assert(sizeof(Quad) == 128, "quad record is one 128-byte line");
+    std::vector<Quad> quads;
+    if (n_pairs > 0 && hn[0].count <= 0) {
+        std::vector<std::pair<int32_t, uint32_t>> work;   // (interior node, its quad)
+        quads.emplace_back();
+        work.emplace_back(0, 0u);
+        while (!work.empty()) {
+            const int32_t node = work.back().first;
+            const uint32_t qi = work.back().second;
+            work.pop_back();
+            int32_t kids[4];
+            int nk = 0;
+            for (int32_t ch = hn[node].leftFirst; ch <= hn[node].leftFirst + 1; ch++) {
+                if (hn[ch].count > 0) kids[nk++] = ch;
+                else { kids[nk++] = hn[ch].leftFirst; kids[nk++] = hn[ch].leftFirst + 1; }
+            }
+            Quad q{};
+            for (int k = 0; k < nk; k++) {
+                const HostNode& kd = hn[kids[k]];
+                for (int a = 0; a < 3; a++) { q.box[a][k] = kd.mn[a]; q.box[3 + a][k] = kd.mx[a]; }
+                if (kd.count > 0) q.entry[k] = leafEntry[kids[k]];
+                else {
+                    q.entry[k] = (uint32_t)quads.size() + 1u;
+                    work.emplace_back(kids[k], (uint32_t)quads.size());
+                    quads.emplace_back();
+                }
+            }
+            quads[qi] = q;
+        }
+        if (quads.size() >= 0x7FFFFFFFu) FAIL(c, PT_E_BAD_BVH, "%zu quad records", quads.size());
+    }
+    if ((rc = upload(&c->d_pairs, pairs.data(), pairs.size() * sizeof(HostNode))) != PT_OK) return rc;
+    if ((rc = upload(&c->d_quads, quads.data(), quads.size() * sizeof(Quad))) != PT_OK) return rc;
+    if ((rc = upload(&c->d_big, big.data(), big.size() * sizeof(uint2))) != PT_OK) return rc;
     if ((rc = upload(&c->d_hot, hot.data(), hot.size() * sizeof(float4))) != PT_OK) return rc;
     if ((rc = upload(&c->d_cold, cold.data(), cold.size() * sizeof(float4))) != PT_OK) return rc;
     if ((rc = upload(&c->d_mats, hm, (size_t)n_mat * 48)) != PT_OK) return rc;
@@ -311,6 +369,8 @@ int pt_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void*
 
     DevScene& sc = c->sc;
     sc.pairs = (const float4*)c->d_pairs;
+    sc.quads = (const float4*)c->d_quads;
+    sc.big = (const uint2*)c->d_big;
     sc.tri_hot = (const float4*)c->d_hot;
     sc.tri_cold = (const float4*)c->d_cold;
     sc.mats = (const float4*)c->d_mats;
@@ -368,6 +428,17 @@ int pt_reset_accumulation(pt_ctx* c) {
     return PT_OK;
 }
 
+// The wide pass over the queue, then the two-wide pass over the rays it set aside (normally none).
+static void launchExtend(pt_ctx* c, bool stats, int cur) {
+    if (stats) {
+        hipLaunchKernelGGL((k_extend<true, false>), dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
+        hipLaunchKernelGGL((k_extend<true, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
+    } else {
+        hipLaunchKernelGGL((k_extend<false, false>), dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
+        hipLaunchKernelGGL((k_extend<false, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
+    }
+}
+
 static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32_t max_bounces, bool generate_only) {
     RenderParams rp{};
     rp.width = c->width;
@@ -412,8 +483,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             rp.last_bounce = (b == max_bounces - 1) ? 1 : 0;
             {
                 StageTimer t(c, 1);
-                if (stats) hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
-                else hipLaunchKernelGGL(k_extend<false>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
+                launchExtend(c, stats, cur);
                 c->host_stats.extend_launches++;
             }
             {
@@ -423,8 +493,13 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             }
             if (rp.nee && c->sc.n_lights > 0) {
                 StageTimer t(c, 3);
-                if (stats) hipLaunchKernelGGL(k_connect<true>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
-                else hipLaunchKernelGGL(k_connect<false>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
+                if (stats) {
+                    hipLaunchKernelGGL((k_connect<true, false>), dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
+                    hipLaunchKernelGGL((k_connect<true, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
+                } else {
+                    hipLaunchKernelGGL((k_connect<false, false>), dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
+                    hipLaunchKernelGGL((k_connect<false, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
+                }
                 c->host_stats.connect_launches++;
             }
             cur ^= 1;
@@ -507,19 +582,23 @@ static int traceCommon(pt_ctx* c, bool anyhit, const float* o_d, const float* tm
     if (n == 0) return PT_OK;
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     float *d_rays = nullptr, *d_tmax = nullptr, *d_t = nullptr, *d_uv = nullptr;
+    uint32_t* d_special = nullptr;
     int32_t* d_tri = nullptr;
     uint8_t* d_occ = nullptr;
     int rc = PT_OK;
-    auto cleanup = [&]() { (void)hipFree(d_rays); (void)hipFree(d_tmax); (void)hipFree(d_t); (void)hipFree(d_uv); (void)hipFree(d_tri); (void)hipFree(d_occ); };
+    auto cleanup = [&]() { (void)hipFree(d_rays); (void)hipFree(d_tmax); (void)hipFree(d_t); (void)hipFree(d_uv); (void)hipFree(d_tri); (void)hipFree(d_occ); (void)hipFree(d_special); };
 #define TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); FAIL(c, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s", #call, hipGetErrorString(_e)); } } while (0)
     TRY(hipMalloc((void**)&d_rays, (size_t)n * 24));
     TRY(hipMemcpyAsync(d_rays, o_d, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    TRY(hipMalloc((void**)&d_special, (size_t)n * 4));
+    hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, 0ull);
     if (anyhit) {
         TRY(hipMalloc((void**)&d_tmax, (size_t)n * 4));
         TRY(hipMalloc((void**)&d_occ, (size_t)n));
         TRY(hipMemcpyAsync(d_tmax, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
         TraceSource src{d_rays, d_tmax, nullptr, nullptr, nullptr, d_occ};
-        hipLaunchKernelGGL(k_trace<true>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl);
+        hipLaunchKernelGGL((k_trace<true, false>), dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl, d_special);
+        hipLaunchKernelGGL((k_trace<true, true>), dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl, d_special);
         TRY(hipGetLastError());
         TRY(hipMemcpyAsync(occ, d_occ, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     } else {
@@ -527,7 +606,8 @@ static int traceCommon(pt_ctx* c, bool anyhit, const float* o_d, const float* tm
         TRY(hipMalloc((void**)&d_t, (size_t)n * 4));
         if (uv) TRY(hipMalloc((void**)&d_uv, (size_t)n * 8));
         TraceSource src{d_rays, nullptr, d_tri, d_t, d_uv, nullptr};
-        hipLaunchKernelGGL(k_trace<false>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl);
+        hipLaunchKernelGGL((k_trace<false, false>), dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl, d_special);
+        hipLaunchKernelGGL((k_trace<false, true>), dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl, d_special);
         TRY(hipGetLastError());
         if (tri) TRY(hipMemcpyAsync(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         if (t) TRY(hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -603,8 +683,7 @@ int pt_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t iters, float
     for (int it = 0; it < iters + 1; it++) {   // the first launch warms caches and is not counted
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, (uint32_t)n, 0ull);
         HIPCHECK(c, hipEventRecord(a, c->stream));
-        if (stats) hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, 0);
-        else hipLaunchKernelGGL(k_extend<false>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, 0);
+        launchExtend(c, stats, 0);
         HIPCHECK(c, hipEventRecord(b, c->stream));
         HIPCHECK(c, hipStreamSynchronize(c->stream));
         float ms = 0.0f;

@@ -11,7 +11,7 @@
 
 #define PT_WAVE 64
 #define PT_STACK_LDS 9       // traversal stack entries (8 bytes each) kept in LDS per lane
-#define PT_STACK_SPILL 55    // further entries in per-lane scratch
+#define PT_STACK_SPILL 87    // further entries in per-lane scratch
 #define PT_STACK_TOTAL (PT_STACK_LDS + PT_STACK_SPILL)
 #define PT_EPSILON 0.00001f  // extend.glsl:4 / shade.glsl:4
 #define PT_PI 3.14159274101257324f
@@ -42,14 +42,23 @@ __device__ __forceinline__ f4 operator/(f4 a, float s) { return mk4(a.x / s, a.y
 __device__ __forceinline__ f4 operator+(f4 a, f4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // ------------------------------------------------------------ scene on device
-// pairs:    one 64-byte record per sibling pair = the host's Node[2k+1], Node[2k+2] verbatim
-//           (Node.cs:5-10), 64-byte aligned so one traversal step is one cache line.
+// pairs:    one 64-byte record per sibling pair = the host's Node[2k+1], Node[2k+2] (Node.cs:5-10),
+//           64-byte aligned so one traversal step is one cache line.  The boxes are verbatim; the
+//           leftFirst word of each node is replaced at upload by the node's traversal entry (see
+//           packLeaf), so a step forms no entries.
+// quads:    one 128-byte record per interior node at an even depth: the boxes of its (up to four)
+//           grandchildren — a child that is a leaf stands for itself — as six float4 columns
+//           (min x, min y, min z, max x, max y, max z), then the four traversal entries (0 = empty
+//           slot) and 16 bytes of padding.  Slot order: the left child's expansion first.
+// big:      (first, count) of the leaves too large for a packed entry, indexed by that entry.
 // tri_hot:  48 B per triangle: (V1.xyz, material bits) (V2-V1, 0) (V3-V1, 0) — all the hit test reads.
 // tri_cold: 48 B per triangle: the three vertex normals, read once per shaded hit.
 // mats:     the host's Material[] verbatim (48 B = 3 x float4).
 // lights:   48 B per emissive triangle: (V1, running area sum) (V2, material bits) (V3, 0).
 struct DevScene {
     const float4* pairs;
+    const float4* quads;
+    const uint2* big;
     const float4* tri_hot;
     const float4* tri_cold;
     const float4* mats;
@@ -66,7 +75,9 @@ struct Ctl {
     uint32_t shadow_count;    // rays in the shadow queue
     uint32_t cursor_extend;   // next unclaimed ray of the running extend launch
     uint32_t cursor_connect;
-    uint32_t pad[3];
+    uint32_t special_extend;  // rays the wide traversal handed to the two-wide one (see traverseWave), per stage
+    uint32_t special_connect;
+    uint32_t cursor_special;
     unsigned long long paths, extend_rays, shadow_rays, extend_steps, extend_tris, shadow_steps, shadow_tris, stack_overflows;
     unsigned long long sched_interior, sched_leaf, sched_refill;   // wave iterations by kind, extend stage, instrumented builds
 };
@@ -258,9 +269,23 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 //   without being visited (closest hit only).
 //   Leaf step: test its triangles in index order, then pop.
 //   A packed leaf holds count-1 in 4 bits and the first triangle in 27; a leaf that does not fit
-//   (more than 15 triangles, or first >= 2^27) is entered through its node index instead and
-//   reads (first, count) back from the node record.
+//   (more than 15 triangles, or first >= 2^27) is entered through an index into a side table of
+//   (first, count) instead.
 //   Closest-hit ties go to the smaller triangle index.
+//
+// Wide traversal (WIDE = true; every ray whose slab distances cannot be NaN)
+//
+//   The same walk over the tree with every other level skipped: an interior entry refers to a
+//   quad record, a step slab-tests its (up to four) boxes, drops the culled ones as above, visits
+//   the survivors nearest first and pushes the rest, farthest first.  The order key of a child is
+//   its entry distance clamped at zero, with the two lowest mantissa bits replaced by the slot
+//   number (keys are unique, any sorting network gives the one order); pushed entries carry the
+//   key with those two bits cleared as their distance.
+//   Skipping a level is exact: for a ray without NaN slab distances a box that passes the slab test
+//   lies inside a parent that passes it too (subtraction and multiplication round monotonically),
+//   and the parent's entry distance is not larger, so the two-wide walk reaches the same leaves.
+//   A ray that can produce NaN (zero, denormal or non-finite components: raySpecial) is not
+//   traversed here: its index is appended to `specialList` and a two-wide launch follows.
 //
 // Per-wave scheduling (free to change: it cannot alter any ray's result)
 //
@@ -285,13 +310,14 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 #endif
 #define PT_NO_RAY 0xFFFFFFFFu
 
-// Entry of the leaf child stored at node index `node` with triangles [first, first+count).
-// Branch-free: both encodings are formed and one is selected.
-__device__ __forceinline__ uint32_t packLeaf(int32_t first, int32_t count, int32_t node) {
-    const bool big = count > PT_LEAF_MAX_COUNT || (uint32_t)first >= PT_LEAF_MAX_FIRST;
-    const uint32_t small = ((uint32_t)(count - 1) << 27) | (uint32_t)first;
-    const uint32_t large = (15u << 27) | (uint32_t)node;
-    return PT_LEAF_FLAG | (big ? large : small);
+// Entry of a leaf with triangles [first, first+count); `bigIndex` is its row in the side table
+// when it does not fit the packed form.  Used by the upload code (host side).
+static inline bool leafFitsPacked(int32_t first, int32_t count) {
+    return count <= PT_LEAF_MAX_COUNT && (uint32_t)first < PT_LEAF_MAX_FIRST;
+}
+static inline uint32_t packLeaf(int32_t first, int32_t count, uint32_t bigIndex) {
+    if (leafFitsPacked(first, count)) return PT_LEAF_FLAG | ((uint32_t)(count - 1) << 27) | (uint32_t)first;
+    return PT_LEAF_FLAG | (15u << 27) | bigIndex;
 }
 
 // Source: struct with
@@ -300,9 +326,12 @@ __device__ __forceinline__ uint32_t packLeaf(int32_t first, int32_t count, int32
 //
 // Lane state: `cur` is the current entry: 0 = no work (ray ended or lane idle), sign bit clear = interior
 // reference, sign bit set = leaf whose remaining triangles are [leafJ, leafEnd).
-template <bool ANYHIT, bool STATS, class Source>
+#define PT_KEY_MISS 0xFFFFFFFFu
+
+template <bool ANYHIT, bool STATS, bool WIDE, class Source>
 __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, const Source& src,
-                                             uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched) {
+                                             uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched,
+                                             uint32_t* specialCount = nullptr, uint32_t* specialList = nullptr) {
     // sched[0..2] (STATS builds): wave iterations spent on interior steps, leaf steps, retire/refill
     const uint32_t lane = laneId();
     const uint32_t totalWaves = gridDim.x * (blockDim.x / PT_WAVE);
@@ -331,10 +360,10 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
         const uint32_t low = e & (PT_LEAF_MAX_FIRST - 1u), cm1 = (e >> 27) & 15u;
         leafJ = (int32_t)low;
         leafEnd = (int32_t)(low + cm1 + 1u);
-        if ((e >> 27) == 31u) {   // leaf too big to pack: `low` is its node index, half of pair record (low-1)/2
-            const float4 rec = sc.pairs[2 * (size_t)(low - 1u) + 1];
-            leafJ = __float_as_int(rec.z);
-            leafEnd = leafJ + __float_as_int(rec.w);
+        if ((e >> 27) == 31u) {   // leaf too big to pack: `low` is its row in the side table
+            const uint2 rec = sc.big[low];
+            leafJ = (int32_t)rec.x;
+            leafEnd = (int32_t)(rec.x + rec.y);
         }
     };
     // pops until an entry whose entry distance is not beyond the best hit turns up (closest hit only:
@@ -404,8 +433,14 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     cur = 0;
                     if (in) {
                         if (sc.root_count > 0) { cur = PT_LEAF_FLAG; leafJ = sc.root_left; leafEnd = sc.root_left + sc.root_count; }
-                        else cur = (uint32_t)sc.root_left;
+                        else cur = WIDE ? 1u : (uint32_t)sc.root_left;   // quad 0, or the node index of the root's left child
                     }
+                }
+                if (WIDE) {
+                    // rays that can produce NaN slab distances go to the two-wide launch that follows
+                    const bool divert = rayIdx != PT_NO_RAY && (idleMask >> lane & 1ull) && special;
+                    const uint32_t at = waveAppend(divert, specialCount);
+                    if (divert) { specialList[at] = rayIdx; rayIdx = PT_NO_RAY; cur = 0; }
                 }
                 const uint32_t nIdle = (uint32_t)__popcll(idleMask);
                 rangeLo += nIdle < avail ? nIdle : avail;
@@ -419,35 +454,77 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             if (interiorMask == 0ull || nLeaf >= PT_LEAF_BATCH) break;
             if (refillable && 64u - (uint32_t)__popcll(interiorMask) - nLeaf >= PT_REFILL_MIN) break;
             if (STATS) sched[0]++;
-            const bool nanSafe = __any((int32_t)cur > 0 && special);
-            if ((int32_t)cur > 0) {
-                if (STATS) (*nsteps)++;
-                const int32_t node = (int32_t)cur;
-                const float4* p = sc.pairs + 2 * (size_t)(node - 1);   // pair (node-1)/2, 4 float4 each
-                const float4 a = p[0], b = p[1], c = p[2], e = p[3];
-                float lt, rt;
-                bool lhit, rhit;
-                if (nanSafe) {
-                    lhit = slabTest<true>(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, &lt);
-                    rhit = slabTest<true>(c.x, c.y, c.z, c.w, e.x, e.y, o, inv, &rt);
-                } else {
-                    lhit = slabTest<false>(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, &lt);
-                    rhit = slabTest<false>(c.x, c.y, c.z, c.w, e.x, e.y, o, inv, &rt);
+            if (WIDE) {
+                if ((int32_t)cur > 0) {
+                    if (STATS) (*nsteps)++;
+                    const float4* p = sc.quads + 8 * (size_t)(cur - 1u);
+                    const float4 mnx = p[0], mny = p[1], mnz = p[2], mxx = p[3], mxy = p[4], mxz = p[5];
+                    const float4 eb = p[6];
+                    uint32_t k0, k1, k2, k3;
+                    uint32_t e0 = __float_as_uint(eb.x), e1 = __float_as_uint(eb.y), e2 = __float_as_uint(eb.z), e3 = __float_as_uint(eb.w);
+#define PT_QUAD_CHILD(K, E, C, SLOT)                                                                          \
+                    {                                                                                          \
+                        float tm;                                                                              \
+                        bool h = slabTest<false>(mnx.C, mny.C, mnz.C, mxx.C, mxy.C, mxz.C, o, inv, &tm);       \
+                        h = h && E != 0u && (ANYHIT ? tm < tlimit : !(tm > best));                             \
+                        const float tk = tm > 0.0f ? tm : 0.0f;                                                \
+                        K = h ? ((__float_as_uint(tk) & ~3u) | SLOT) : PT_KEY_MISS;                            \
+                    }
+                    PT_QUAD_CHILD(k0, e0, x, 0u)
+                    PT_QUAD_CHILD(k1, e1, y, 1u)
+                    PT_QUAD_CHILD(k2, e2, z, 2u)
+                    PT_QUAD_CHILD(k3, e3, w, 3u)
+#undef PT_QUAD_CHILD
+#define PT_CSWAP(KA, EA, KB, EB)                                                  \
+                    {                                                              \
+                        const bool sw = KB < KA;                                   \
+                        const uint32_t ka = sw ? KB : KA, kb = sw ? KA : KB;       \
+                        const uint32_t ea = sw ? EB : EA, eb2 = sw ? EA : EB;      \
+                        KA = ka; KB = kb; EA = ea; EB = eb2;                       \
+                    }
+                    PT_CSWAP(k0, e0, k1, e1)
+                    PT_CSWAP(k2, e2, k3, e3)
+                    PT_CSWAP(k0, e0, k2, e2)
+                    PT_CSWAP(k1, e1, k3, e3)
+                    PT_CSWAP(k1, e1, k2, e2)
+#undef PT_CSWAP
+                    // survivors beyond the nearest: pushed farthest first
+                    if (k1 != PT_KEY_MISS) {
+                        if (k3 != PT_KEY_MISS) push(e3, __uint_as_float(k3 & ~3u));
+                        if (k2 != PT_KEY_MISS) push(e2, __uint_as_float(k2 & ~3u));
+                        push(e1, __uint_as_float(k1 & ~3u));
+                    }
+                    if (k0 != PT_KEY_MISS) enter(e0);
+                    else popNext();
                 }
-                if (ANYHIT) { lhit = lhit && lt < tlimit; rhit = rhit && rt < tlimit; }
-                else { lhit = lhit && !(lt > best); rhit = rhit && !(rt > best); }
-                const int32_t lfirst = __float_as_int(b.z), lcount = __float_as_int(b.w);
-                const int32_t rfirst = __float_as_int(e.z), rcount = __float_as_int(e.w);
-                const uint32_t eL = lcount > 0 ? packLeaf(lfirst, lcount, node) : (uint32_t)lfirst;
-                const uint32_t eR = rcount > 0 ? packLeaf(rfirst, rcount, node + 1) : (uint32_t)rfirst;
-                // nearer surviving child next, the other pushed with its entry distance
-                const bool rightFirst = rhit && (!lhit || rt < lt);
-                const uint32_t nearE = rightFirst ? eR : eL, farE = rightFirst ? eL : eR;
-                const float farT = rightFirst ? lt : rt;
-                if (lhit && rhit) push(farE, farT);
-                if (lhit || rhit) enter(nearE);
-                else popNext();
-            }
+            } else {
+                const bool nanSafe = __any((int32_t)cur > 0 && special);
+                if ((int32_t)cur > 0) {
+                    if (STATS) (*nsteps)++;
+                    const int32_t node = (int32_t)cur;
+                    const float4* p = sc.pairs + 2 * (size_t)(node - 1);   // pair (node-1)/2, 4 float4 each
+                    const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+                    float lt, rt;
+                    bool lhit, rhit;
+                    if (nanSafe) {
+                        lhit = slabTest<true>(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, &lt);
+                        rhit = slabTest<true>(c.x, c.y, c.z, c.w, e.x, e.y, o, inv, &rt);
+                    } else {
+                        lhit = slabTest<false>(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, &lt);
+                        rhit = slabTest<false>(c.x, c.y, c.z, c.w, e.x, e.y, o, inv, &rt);
+                    }
+                    if (ANYHIT) { lhit = lhit && lt < tlimit; rhit = rhit && rt < tlimit; }
+                    else { lhit = lhit && !(lt > best); rhit = rhit && !(rt > best); }
+                    const uint32_t eL = __float_as_uint(b.z), eR = __float_as_uint(e.z);   // entries, formed at upload
+                    // nearer surviving child next, the other pushed with its entry distance
+                    const bool rightFirst = rhit && (!lhit || rt < lt);
+                    const uint32_t nearE = rightFirst ? eR : eL, farE = rightFirst ? eL : eR;
+                    const float farT = rightFirst ? lt : rt;
+                    if (lhit && rhit) push(farE, farT);
+                    if (lhit || rhit) enter(nearE);
+                    else popNext();
+                }
+                    }
         }
         // ---- triangle tests, one per waiting lane and iteration
         for (;;) {

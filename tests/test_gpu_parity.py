@@ -121,6 +121,28 @@ def test_axis_aligned_and_degenerate_rays(ob, bundled, wf_bundled):
     assert (g["tri"][differs] < lit["tri"][differs]).all()
 
 
+def test_special_rays_in_the_extend_stage(ob, bundled, wf_bundled):
+    """The wide traversal sets rays with NaN-capable slab distances aside for the two-wide pass: a queue that mixes
+    both kinds must come out exactly as the per-ray queries do."""
+    rng = np.random.default_rng(5)
+    n = 4096
+    rays = np.zeros((n, 6), np.float32)
+    rays[:, 0:3] = rng.uniform(-8, 8, (n, 3)).astype(np.float32) + np.array([0, 9, 0], np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays[:, 3:6] = d / np.sqrt((d * d).sum(1, dtype=np.float32))[:, None]
+    special = rng.random(n) < 0.3
+    axis = rng.integers(0, 3, n)
+    rays[special, 3 + axis[special]] = 0.0          # zero direction component
+    rays[rng.random(n) < 0.02, 3:6] = [0, -1, 0]    # straight down
+    _, hits = wf_bundled.bench_extend(rays, iters=1)
+    tri, t = hits["tri"], hits["t"]
+    can = bundled.intersect(rays, "canonical")
+    lit = bundled.intersect(rays, "literal")
+    assert np.array_equal(tri, can["tri"]) and np.array_equal(bits(t), bits(can["t"]))
+    assert np.array_equal(bits(t), bits(lit["t"]))
+    assert special.sum() > 1000 and (tri >= 0).sum() > 1000
+
+
 def test_tiny_and_empty_scenes(pa, ob):
     # 2 triangles: the root stays a leaf (Count < 3, Accelerator.cs:138)
     s = ob.Scene(pa_assets())
