@@ -18,6 +18,7 @@
 #define PT_INVPI 0.318309873342514038f
 #define PT_INF __builtin_huge_valf()
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -462,6 +463,30 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     const float4 eb = p[6];
                     uint32_t k0, k1, k2, k3;
                     uint32_t e0 = __float_as_uint(eb.x), e1 = __float_as_uint(eb.y), e2 = __float_as_uint(eb.z), e3 = __float_as_uint(eb.w);
+#ifdef PT_PACKED_SLAB
+                    // slab distances of two children per packed instruction: (plane - o) * inv, Box.cs:51-79
+                    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+                    const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+#define PT_PLANES(LO, HI, A, B)                                                          \
+                    const v2f LO##x = (v2f{mnx.A, mnx.B} - ox) * ix, HI##x = (v2f{mxx.A, mxx.B} - ox) * ix; \
+                    const v2f LO##y = (v2f{mny.A, mny.B} - oy) * iy, HI##y = (v2f{mxy.A, mxy.B} - oy) * iy; \
+                    const v2f LO##z = (v2f{mnz.A, mnz.B} - oz) * iz, HI##z = (v2f{mxz.A, mxz.B} - oz) * iz;
+                    PT_PLANES(a01, b01, x, y)
+                    PT_PLANES(a23, b23, z, w)
+#undef PT_PLANES
+#define PT_QUAD_CHILD(K, E, LO, HI, H, SLOT)                                                                               \
+                    {                                                                                                       \
+                        const float tm = fmaxf(fmaxf(fminf(LO##x.H, HI##x.H), fminf(LO##y.H, HI##y.H)), fminf(LO##z.H, HI##z.H)); \
+                        const float tx = fminf(fminf(fmaxf(LO##x.H, HI##x.H), fmaxf(LO##y.H, HI##y.H)), fmaxf(LO##z.H, HI##z.H)); \
+                        const bool h = tx > 0.0f && tm < tx && E != 0u && (ANYHIT ? tm < tlimit : !(tm > best));            \
+                        const float tk = tm > 0.0f ? tm : 0.0f;                                                             \
+                        K = h ? ((__float_as_uint(tk) & ~3u) | SLOT) : PT_KEY_MISS;                                         \
+                    }
+                    PT_QUAD_CHILD(k0, e0, a01, b01, x, 0u)
+                    PT_QUAD_CHILD(k1, e1, a01, b01, y, 1u)
+                    PT_QUAD_CHILD(k2, e2, a23, b23, x, 2u)
+                    PT_QUAD_CHILD(k3, e3, a23, b23, y, 3u)
+#else
 #define PT_QUAD_CHILD(K, E, C, SLOT)                                                                          \
                     {                                                                                          \
                         float tm;                                                                              \
@@ -474,6 +499,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     PT_QUAD_CHILD(k1, e1, y, 1u)
                     PT_QUAD_CHILD(k2, e2, z, 2u)
                     PT_QUAD_CHILD(k3, e3, w, 3u)
+#endif
 #undef PT_QUAD_CHILD
 #define PT_CSWAP(KA, EA, KB, EB)                                                  \
                     {                                                              \
@@ -488,11 +514,20 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     PT_CSWAP(k1, e1, k3, e3)
                     PT_CSWAP(k1, e1, k2, e2)
 #undef PT_CSWAP
-                    // survivors beyond the nearest: pushed farthest first
+                    // survivors beyond the nearest: pushed farthest first (sorted: k3 present implies k2, k2 implies k1)
                     if (k1 != PT_KEY_MISS) {
-                        if (k3 != PT_KEY_MISS) push(e3, __uint_as_float(k3 & ~3u));
-                        if (k2 != PT_KEY_MISS) push(e2, __uint_as_float(k2 & ~3u));
-                        push(e1, __uint_as_float(k1 & ~3u));
+                        const int np = 1 + (k2 != PT_KEY_MISS ? 1 : 0) + (k3 != PT_KEY_MISS ? 1 : 0);
+                        if (sp + 3 <= PT_STACK_LDS) {
+                            uint2* const at = mystack + sp * PT_WAVE;
+                            if (np == 3) at[0] = make_uint2(e3, k3 & ~3u);
+                            if (np >= 2) at[(np - 2) * PT_WAVE] = make_uint2(e2, k2 & ~3u);
+                            at[(np - 1) * PT_WAVE] = make_uint2(e1, k1 & ~3u);
+                            sp += np;
+                        } else {
+                            if (np == 3) push(e3, __uint_as_float(k3 & ~3u));
+                            if (np >= 2) push(e2, __uint_as_float(k2 & ~3u));
+                            push(e1, __uint_as_float(k1 & ~3u));
+                        }
                     }
                     if (k0 != PT_KEY_MISS) enter(e0);
                     else popNext();
