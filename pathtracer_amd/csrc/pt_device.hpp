@@ -10,8 +10,9 @@
 #include <type_traits>
 
 #define PT_WAVE 64
-#define PT_STACK_LDS 9       // traversal stack entries (8 bytes each) kept in LDS per lane
-#define PT_STACK_SPILL 87    // further entries in per-lane scratch
+#define PT_STACK_LDS 8       // traversal stack entries (8 bytes each) kept in LDS per lane
+#define PT_STACK_SPILL 88    // further entries in per-lane scratch
+#define PT_LEAFQ_WORDS 160   // 8-byte words of LDS per wave for the leaf phase: 64 result keys, 64 (u, v), 64 owner lanes
 #define PT_STACK_TOTAL (PT_STACK_LDS + PT_STACK_SPILL)
 #define PT_EPSILON 0.00001f  // extend.glsl:4 / shade.glsl:4
 #define PT_PI 3.14159274101257324f
@@ -49,8 +50,10 @@ __device__ __forceinline__ f4 operator+(f4 a, f4 b) { return mk4(a.x + b.x, a.y 
 //           packLeaf), so a step forms no entries.
 // quads:    one 128-byte record per interior node at an even depth: the boxes of its (up to four)
 //           grandchildren — a child that is a leaf stands for itself — as six float4 columns
-//           (min x, min y, min z, max x, max y, max z), then the four traversal entries (0 = empty
-//           slot) and 16 bytes of padding.  Slot order: the left child's expansion first.
+//           (min x, min y, min z, max x, max y, max z), then the four traversal entries and 16
+//           bytes of padding.  Slot order: the left child's expansion first.  An empty slot holds the
+//           point box at the origin, which no ray passes: its near and far distances coincide on
+//           every axis, so "entry distance < exit distance" cannot hold.
 // big:      (first, count) of the leaves too large for a packed entry, indexed by that entry.
 // tri_hot:  48 B per triangle: (V1.xyz, material bits) (V2-V1, 0) (V3-V1, 0) — all the hit test reads.
 // tri_cold: 48 B per triangle: the three vertex normals, read once per shaded hit.
@@ -202,6 +205,21 @@ __device__ __forceinline__ void waveAdd64(unsigned long long* counter, uint32_t 
     if (laneId() == 0) atomicAdd(counter, total);
 }
 
+// Inclusive prefix sum over the 64 lanes (all lanes must be active).
+__device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v) {
+    // within rows of 16 lanes: row_shr:n with out-of-row lanes reading 0
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    // across rows
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+    const uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const uint32_t row = laneId() >> 4;
+    return v + (row > 0u ? r0 : 0u) + (row > 1u ? r1 : 0u) + (row > 2u ? r2 : 0u);
+}
+
 // A slab distance can be NaN only for a ray with a zero/denormal/non-finite direction
 // component or a non-finite origin; such rays take the NaN-rejecting traversal.
 __device__ __forceinline__ bool raySpecial(f3 o, f3 d) {
@@ -268,7 +286,8 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 //   with none, `cur` is popped (the ray ends on an empty stack).  Pushed entries carry their entry
 //   distance; a popped entry whose distance has meanwhile fallen beyond the best hit is discarded
 //   without being visited (closest hit only).
-//   Leaf step: test its triangles in index order, then pop.
+//   Leaf step: test its triangles (all of them for a closest-hit ray; up to the first occluder in
+//   index order for an any-hit ray), then pop.
 //   A packed leaf holds count-1 in 4 bits and the first triangle in 27; a leaf that does not fit
 //   (more than 15 triangles, or first >= 2^27) is entered through an index into a side table of
 //   (first, count) instead.
@@ -291,8 +310,10 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 // Per-wave scheduling (free to change: it cannot alter any ray's result)
 //
 //   Each iteration of the wave does ONE kind of work under a wave-uniform branch: an interior
-//   step for every lane holding an interior entry, or one triangle test for every lane holding a
-//   leaf.  Lanes that reach a leaf wait until PT_LEAF_BATCH lanes are waiting (or nobody is left
+//   step for every lane holding an interior entry, or a leaf phase: the triangles of the waiting
+//   leaves (at most 64, in lane then index order) are dealt one to a lane, each lane tests its
+//   triangle against the owner's ray (fetched with lane permutes), results return to the owners
+//   through an LDS minimum on (distance, triangle index), and owners whose leaf is finished pop.  Lanes that reach a leaf wait until PT_LEAF_BATCH lanes are waiting (or nobody is left
 //   stepping), so both code paths run with many lanes active instead of a few.
 //   Lanes are persistent: a lane whose ray has ended stores the result and takes the next ray of
 //   the wave's private range; the range is replenished 256 rays at a time from the shared cursor
@@ -330,7 +351,7 @@ static inline uint32_t packLeaf(int32_t first, int32_t count, uint32_t bigIndex)
 #define PT_KEY_MISS 0xFFFFFFFFu
 
 template <bool ANYHIT, bool STATS, bool WIDE, class Source>
-__device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, const Source& src,
+__device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, unsigned long long* leafq, const Source& src,
                                              uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched,
                                              uint32_t* specialCount = nullptr, uint32_t* specialList = nullptr) {
     // sched[0..2] (STATS builds): wave iterations spent on interior steps, leaf steps, retire/refill
@@ -478,9 +499,9 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     {                                                                                                       \
                         const float tm = fmaxf(fmaxf(fminf(LO##x.H, HI##x.H), fminf(LO##y.H, HI##y.H)), fminf(LO##z.H, HI##z.H)); \
                         const float tx = fminf(fminf(fmaxf(LO##x.H, HI##x.H), fmaxf(LO##y.H, HI##y.H)), fmaxf(LO##z.H, HI##z.H)); \
-                        const bool h = tx > 0.0f && tm < tx && E != 0u && (ANYHIT ? tm < tlimit : !(tm > best));            \
-                        const float tk = tm > 0.0f ? tm : 0.0f;                                                             \
-                        K = h ? ((__float_as_uint(tk) & ~3u) | SLOT) : PT_KEY_MISS;                                         \
+                        const bool h = tx > 0.0f && tm < tx && (ANYHIT ? tm < tlimit : !(tm > best));                       \
+                        const int32_t tb = __float_as_int(tm);                                                              \
+                        K = h ? (((uint32_t)(tb > 0 ? tb : 0) & ~3u) | SLOT) : PT_KEY_MISS;                                 \
                     }
                     PT_QUAD_CHILD(k0, e0, a01, b01, x, 0u)
                     PT_QUAD_CHILD(k1, e1, a01, b01, y, 1u)
@@ -491,9 +512,9 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     {                                                                                          \
                         float tm;                                                                              \
                         bool h = slabTest<false>(mnx.C, mny.C, mnz.C, mxx.C, mxy.C, mxz.C, o, inv, &tm);       \
-                        h = h && E != 0u && (ANYHIT ? tm < tlimit : !(tm > best));                             \
-                        const float tk = tm > 0.0f ? tm : 0.0f;                                                \
-                        K = h ? ((__float_as_uint(tk) & ~3u) | SLOT) : PT_KEY_MISS;                            \
+                        h = h && (ANYHIT ? tm < tlimit : !(tm > best));                                        \
+                        const int32_t tb = __float_as_int(tm);   /* negative distances (and -0) clamp to +0 */ \
+                        K = h ? (((uint32_t)(tb > 0 ? tb : 0) & ~3u) | SLOT) : PT_KEY_MISS;                    \
                     }
                     PT_QUAD_CHILD(k0, e0, x, 0u)
                     PT_QUAD_CHILD(k1, e1, y, 1u)
@@ -570,19 +591,72 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             if (nInterior != 0u && nLeaf < PT_LEAF_BATCH) break;
             if (refillable && 64u - nInterior - nLeaf >= PT_REFILL_MIN) break;
             if (STATS) sched[1]++;
-            if ((int32_t)cur < 0) {
-                const int32_t j = leafJ;
+            unsigned long long* const resKey = leafq;                       // [64] best (distance bits, triangle) per owner
+            float2* const resUv = (float2*)(leafq + 64);                    // [64] its barycentrics
+            uint32_t* const ownerOf = (uint32_t*)(leafq + 128);             // [64] owner lane of each dealt triangle
+            const bool owner = (int32_t)cur < 0;
+            const uint32_t left = owner ? (uint32_t)(leafEnd - leafJ) : 0u;
+            const uint32_t cnt = left < 64u ? left : 64u;
+            const uint32_t incl = waveInclusiveScan(cnt);
+            const uint32_t pre = incl - cnt;
+            const uint32_t mine = pre >= 64u ? 0u : (cnt < 64u - pre ? cnt : 64u - pre);   // this owner's triangles in this phase
+            const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t dealt = all < 64u ? all : 64u;
+            if (mine != 0u) resKey[lane] = ~0ull;
+            for (uint32_t k = 0; __any(k < mine); k++)
+                if (k < mine) ownerOf[pre + k] = lane;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- one triangle per lane
+            const bool busy = lane < dealt;
+            const uint32_t own = busy ? ownerOf[lane] : lane;
+            const uint32_t preO = (uint32_t)__shfl((int)pre, (int)own);
+            const int32_t jO = __shfl(leafJ, (int)own);
+            const f3 po = mk3(__shfl(o.x, (int)own), __shfl(o.y, (int)own), __shfl(o.z, (int)own));
+            const f3 pd = mk3(__shfl(d.x, (int)own), __shfl(d.y, (int)own), __shfl(d.z, (int)own));
+            const float limO = ANYHIT ? __shfl(tlimit, (int)own) : 0.0f;
+            const uint32_t kth = lane - preO;
+            const int32_t j = jO + (int32_t)kth;
+            bool hit = false;
+            float tt = 0.0f, tu = 0.0f, tv = 0.0f;
+            if (busy) {
                 const float4* tp = sc.tri_hot + 3 * (size_t)j;
                 const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                if (STATS) (*ntris)++;
-                float tt, tu, tv;
-                if (triangleTest(q0, q1, q2, o, d, &tt, &tu, &tv)) {
-                    if (ANYHIT) { if (tt < tlimit) occluded = true; }
-                    else if (tt < best || (tt == best && j < bestTri)) { best = tt; bestTri = j; bu = tu; bv = tv; }
-                }
-                if (ANYHIT && occluded) cur = 0;
-                else if (++leafJ == leafEnd) popNext();
+                hit = triangleTest(q0, q1, q2, po, pd, &tt, &tu, &tv);
+                if (ANYHIT) hit = hit && tt < limO;
             }
+            // closest: smallest (distance, triangle index); any-hit: first occluder in index order
+            const unsigned long long key = ANYHIT ? (unsigned long long)kth : (((unsigned long long)__float_as_uint(tt) << 32) | (uint32_t)j);
+            if (hit) atomicMin(&resKey[own], key);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!ANYHIT) {
+                if (hit && resKey[own] == key) resUv[own] = make_float2(tu, tv);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ---- owners take their results
+            if (mine != 0u) {
+                const unsigned long long r = resKey[lane];
+                if (ANYHIT) {
+                    if (r != ~0ull) occluded = true;
+                    if (STATS) (*ntris) += (r != ~0ull) ? (uint32_t)r + 1u : mine;
+                } else {
+                    if (STATS) (*ntris) += mine;
+                    if (r != ~0ull) {
+                        const float rt = __uint_as_float((uint32_t)(r >> 32));
+                        const int32_t rj = (int32_t)(uint32_t)r;
+                        if (rt < best || (rt == best && rj < bestTri)) {
+                            const float2 uv = resUv[lane];
+                            best = rt; bestTri = rj; bu = uv.x; bv = uv.y;
+                        }
+                    }
+                }
+                leafJ += (int32_t)mine;
+                if (ANYHIT && occluded) cur = 0;
+                else if (leafJ == leafEnd) popNext();
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }

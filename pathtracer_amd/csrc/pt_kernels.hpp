@@ -109,7 +109,9 @@ struct ListSource {
 template <bool STATS, bool SPECIAL>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
+    __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
+    unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
     const uint32_t n = SPECIAL ? ctl->special_extend : ctl->count[cur];
     if (SPECIAL && n == 0u) return;
     if (!SPECIAL && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -130,9 +132,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene
         ListSource<ExtendSource> ls;
         ls.inner = src;
         ls.list = q.special;
-        traverseWave<false, STATS, false>(sc, n, &ctl->cursor_special, lstack, ls, &steps, &tris, &overflow, sched);
+        traverseWave<false, STATS, false>(sc, n, &ctl->cursor_special, lstack, leafq, ls, &steps, &tris, &overflow, sched);
     } else {
-        traverseWave<false, STATS, true>(sc, n, &ctl->cursor_extend, lstack, src, &steps, &tris, &overflow, sched, &ctl->special_extend, q.special);
+        traverseWave<false, STATS, true>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, &ctl->special_extend, q.special);
     }
     if (STATS) {
         waveAdd64(&ctl->extend_steps, steps);
@@ -171,7 +173,9 @@ struct ConnectSource {
 template <bool STATS, bool SPECIAL>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScene sc, Queues q, Ctl* ctl) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
+    __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
+    unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
     const uint32_t n = SPECIAL ? ctl->special_connect : ctl->shadow_count;
     if (SPECIAL && n == 0u) return;
     if (!SPECIAL && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->shadow_rays, (unsigned long long)n);
@@ -186,9 +190,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScen
         ListSource<ConnectSource> ls;
         ls.inner = src;
         ls.list = q.special;
-        traverseWave<true, STATS, false>(sc, n, &ctl->cursor_special, lstack, ls, &steps, &tris, &overflow, sched);
+        traverseWave<true, STATS, false>(sc, n, &ctl->cursor_special, lstack, leafq, ls, &steps, &tris, &overflow, sched);
     } else {
-        traverseWave<true, STATS, true>(sc, n, &ctl->cursor_connect, lstack, src, &steps, &tris, &overflow, sched, &ctl->special_connect, q.special);
+        traverseWave<true, STATS, true>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, &ctl->special_connect, q.special);
     }
     if (STATS) {
         waveAdd64(&ctl->shadow_steps, steps);
@@ -523,16 +527,18 @@ struct TraceSource {
 template <bool ANYHIT, bool SPECIAL>
 __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src, int n, Ctl* ctl, uint32_t* special) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
+    __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
+    unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
     uint32_t steps = 0, tris = 0, overflow = 0;
     uint32_t sched[3] = {0, 0, 0};
     if (SPECIAL) {
         ListSource<TraceSource> ls;
         ls.inner = src;
         ls.list = special;
-        traverseWave<ANYHIT, false, false>(sc, ctl->special_extend, nullptr, lstack, ls, &steps, &tris, &overflow, sched);
+        traverseWave<ANYHIT, false, false>(sc, ctl->special_extend, nullptr, lstack, leafq, ls, &steps, &tris, &overflow, sched);
     } else {
-        traverseWave<ANYHIT, false, true>(sc, (uint32_t)n, nullptr, lstack, src, &steps, &tris, &overflow, sched, &ctl->special_extend, special);
+        traverseWave<ANYHIT, false, true>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, &ctl->special_extend, special);
     }
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
 }
