@@ -150,13 +150,14 @@ def main():
     cam, pos, tgt = camera_for(args.workload, w, h, wf)
     fs = cam.frame_state(pos, tgt, frames=1, samples=0)
 
+    gather = tiles.AccumulatorGather(wf, dst=0) if world > 1 else None
+
     def step():
         wf.invoke(fs, spp=spp_total, max_bounces=bounces, wait=False)
         fs["frames"] += spp_total
         fs["samples"] += spp_total
-        if world > 1:
-            wf.synchronize()
-            tiles.gather_accumulators(tiles.accumulator_tensor(wf), dst=0)
+        if gather is not None:
+            gather()   # the image's tiles to rank 0; RCCL moves them while the next image renders
 
     def sync_all():
         wf.synchronize()

@@ -60,6 +60,40 @@ def gather_accumulators(local, dst=0, group=None):
     return None
 
 
+class AccumulatorGather:
+    """Once-per-image gather of one context's accumulator with preallocated buffers.
+
+    Each call waits for the context's own stream, snapshots the accumulator (a device copy on torch's
+    current stream) and gathers the snapshot.  With the "nccl" backend nothing blocks the host after the
+    snapshot is queued: RCCL reads the snapshot on its own stream while the caller already renders the next
+    image into the live accumulator, and the next call's snapshot is ordered after this gather by torch's
+    stream semantics.  `result` is the (world, n, 4) tensor on `dst` (None elsewhere); it is complete once
+    torch's current stream has caught up (torch.cuda.synchronize()).
+    """
+
+    def __init__(self, wf, dst=0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.wf, self.dst, self.group = wf, dst, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.on_device = dist.get_backend(group) == "nccl"
+        self.local = accumulator_tensor(wf)
+        dev = self.local.device if self.on_device else torch.device("cpu")
+        self.snapshot = torch.empty(self.local.shape, dtype=self.local.dtype, device=dev)
+        self.result = None
+        if self.rank == dst:
+            self.result = torch.empty((self.world,) + tuple(self.local.shape), dtype=self.local.dtype, device=dev)
+
+    def __call__(self):
+        import torch.distributed as dist
+        self.wf.synchronize()
+        self.snapshot.copy_(self.local, non_blocking=self.on_device)
+        parts = list(self.result.unbind(0)) if self.rank == self.dst else None
+        dist.gather(self.snapshot, parts, dst=self.dst, group=self.group)
+        return self.result
+
+
 def gather_image(wf, samples, dst=0, group=None):
     """Synchronise the context, gather all ranks' tiles and assemble the image on `dst` (None elsewhere)."""
     import torch

@@ -379,9 +379,25 @@ if rank == 0:
     ref.invoke(fs, spp=spp, max_bounces=4)
     want = ref.read_image()
     assert np.array_equal(img.view(np.uint32), want.view(np.uint32)), "tile-sharded image differs from the single-context image"
-    print("RANKS_OK")
 else:
     assert img is None
+# a second image through the preallocated gather bench.py uses
+fs["frames"] += spp
+fs["samples"] += spp
+gather = tiles.AccumulatorGather(wf, dst=0)
+wf.invoke(fs, spp=spp, max_bounces=4, wait=False)
+res = gather()
+torch.cuda.synchronize()
+if rank == 0:
+    dev = res.to("cuda")
+    torch.cuda.synchronize()
+    img2 = wf.assemble_tiles(dev.data_ptr(), world, 2 * spp)
+    ref.invoke(fs, spp=spp, max_bounces=4)
+    want2 = ref.read_image()
+    assert np.array_equal(img2.view(np.uint32), want2.view(np.uint32)), "second gathered image differs"
+    print("RANKS_OK")
+else:
+    assert res is None
 dist.barrier()
 wf.close()
 dist.destroy_process_group()
