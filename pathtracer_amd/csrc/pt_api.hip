@@ -106,7 +106,7 @@ uint32_t chooseBatch(const pt_ctx* c, uint32_t spp) {
         // enough paths per launch to fill 256 CUs x 32 waves several times over
         const uint32_t target = 32u << 20;
         want = std::max(1u, target / std::max(1u, c->slots));
-        want = std::min(want, 64u);
+        want = std::min(want, 1024u);   // tile-sharded ranks own few slots and batch many samples
     }
     // queue indices are 32-bit: never more than 2^30 paths in flight
     const uint32_t cap = std::max(1u, (1u << 30) / std::max(1u, c->slots));

@@ -81,6 +81,38 @@ def test_host_meshes_materials_floor(host, ob):
     assert s.get_material_index(material((0.1, 0.2, 0.3, 0))) == n   # a new one is appended
 
 
+def test_host_synthetic_large_scene_generators(host):
+    """The stand-ins for the larger BASELINE scenes: bundled recipe + extra bunnies, and instanced bunnies.  Their BVHs
+    obey the builder's invariants and are independent of the thread count."""
+    s = host.Scene()
+    s.initialize_scene_extended(11, 19)
+    s.build(4)
+    c = s.counts()
+    assert c["triangles"] == 259600            # 165,208 + 19 x 4,968
+    mats, tris, nodes = s.arrays()
+    base = host.Scene()
+    base.initialize_scene(11)
+    base.build(1)
+    bt = base.arrays()[1]
+    # the same random stream: the first 60 objects are the bundled scene's (the build reorders triangles, so compare as sets)
+    key = lambda t: np.sort(np.ascontiguousarray(t).view(np.uint8).reshape(t.size, -1).view("V112").ravel())
+    assert np.isin(key(bt), key(tris)).all()
+    for count in (1, 9):
+        a, b = host.Scene(), host.Scene()
+        a.generate_instances(count, 11)
+        b.generate_instances(count, 11)
+        a.build(1)
+        b.build(4)
+        assert same(a.arrays(), b.arrays())
+        m, t, n = a.arrays()
+        assert t.size == count * 4968 + 2 and (n.size & 1) == 1
+        leaves = n[n["count"] > 0]
+        order = np.argsort(leaves["left_first"])
+        first, cnt = leaves["left_first"][order], leaves["count"][order]
+        assert first[0] == 0 and np.array_equal(first[1:], (first + cnt)[:-1]) and first[-1] + cnt[-1] == t.size   # leaves tile [0, n)
+        assert (m["emissive"][:, :3].sum(1) > 0).sum() >= 1
+
+
 def test_host_obj_text_loader(host, ob, tmp_path):
     """The OBJ/MTL text path of the host mirror (Mesh.cs:72-329) on a file written here: quads, negative
     indices, missing normals, tabs, a material library."""
