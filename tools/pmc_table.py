@@ -24,4 +24,4 @@ for f in files:
           "| TCP accesses/clk/CU %.2f" % (v["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256 / g),
           "| VALU issue %.2f" % (v["SQ_INSTS_VALU"] * 4 / (1024 * g)), "| SALU/VALU %.2f" % (v["SQ_INSTS_SALU"] / v["SQ_INSTS_VALU"]),
           "| lanes/VALU %.1f" % (v["SQ_THREAD_CYCLES_VALU"] / v["SQ_ACTIVE_INST_VALU"] if v.get("SQ_ACTIVE_INST_VALU") else 0),
-          "| waves %.0f" % v["SQ_WAVES"], "| wave occupancy/SIMD %.1f" % (v["SQ_WAVE_CYCLES"] / (1024 * g)))
+          "| waves %.0f" % v["SQ_WAVES"], "| waves/SIMD, time average (SQ_WAVE_CYCLES ticks every 4th clock) %.1f" % (4 * v["SQ_WAVE_CYCLES"] / (1024 * g)))
