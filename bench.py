@@ -4,7 +4,7 @@
 One step = one frame: `spp` samples per pixel of the workload through
 generate -> {extend -> shade -> connect} x bounces on every rank's tiles (scene and rays resident
 in HBM; the device-to-host image read is outside the timed region).  Default workload is
-BASELINE.json configs[1]: the reference's bundled scene, 1920x1080, 16 spp, 4 bounces, NEE.
+the headline configuration: the reference's bundled scene, 1920x1080, 16 spp, 4 bounces, NEE.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -29,7 +29,7 @@ WORKLOADS = {
     # name: (description, width, height, spp, bounces, nee)
     "bundled": ("bundled scene (Game.InitializeScene(11), 165,208 triangles), 1920x1080, 16 spp, 4 bounces, NEE", 1920, 1080, 16, 4, 1),
     "soup1m": ("synthetic 1M-triangle random soup + SAH BVH, 1920x1080, 8 spp, 4 bounces, diffuse only, NEE", 1920, 1080, 8, 4, 1),
-    # the other BASELINE.json configs (parity/measurement cases, not the default bench line)
+    # the other benchmark configurations (parity/measurement cases, not the default bench line)
     "c1": ("bundled scene, 512x512, 1 spp, primary + 1 bounce, no NEE (the reference's own setting)", 512, 512, 1, 2, 0),
     "c3": ("synthetic 1M-triangle random soup + SAH BVH, 1920x1080, 64 spp, 4 bounces, diffuse only, NEE", 1920, 1080, 64, 4, 1),
     "c4": ("bundled recipe + 19 bunnies (259,600 triangles, Sponza-scale), 3840x2160, 256 spp in steps of 32, 4 bounces, NEE", 3840, 2160, 32, 4, 1),

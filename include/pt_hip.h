@@ -129,6 +129,15 @@ int pt_bench_extend(pt_ctx* ctx, const float* o_d, int32_t n, int32_t iters, flo
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
 int pt_reset_stats(pt_ctx* ctx);
 
+/* Accelerator.Build on the GPU, PathTracer/Accelerator.cs:113-310: binned SAH (8 bins, leaves below 3 primitives).
+ * triangles_in: n_tri Triangle records in Accelerator.AddTriangle order.  triangles_out (n_tri records) and nodes_out
+ * (room for node_capacity >= max(1, 2*n_tri-1) Node records) receive what Build leaves in its two Buffer<T> mirrors —
+ * the same bytes the one-thread CPU build produces — ready for pt_upload_scene and for the host's own
+ * Accelerator.Intersect.  *n_nodes: nodes written.  build_ms (may be NULL): device time of the build itself,
+ * without the transfers. */
+int pt_build_bvh(pt_ctx* ctx, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out, int32_t node_capacity,
+                 int32_t* n_nodes, float* build_ms);
+
 /* Runtime switches: key is one of PT_OPT_*; takes effect at the next pt_render. */
 enum { PT_OPT_NEE = 1, PT_OPT_RNG_MODE = 2, PT_OPT_TRAVERSAL_STATS = 3, PT_OPT_STAGE_TIMING = 4, PT_OPT_SAMPLES_PER_BATCH = 5,
        PT_OPT_TRAVERSE_BLOCKS_PER_CU = 6 /* resident 256-thread blocks per CU of the traversal kernels; 0 = the default (at most 7) */ };

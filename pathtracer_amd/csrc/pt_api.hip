@@ -4,6 +4,7 @@
 // bounce), statistics.
 #include "pt_hip.h"
 #include "pt_kernels.hpp"
+#include "pt_build.hpp"
 #include <string>
 #include <vector>
 #include <cstring>
@@ -703,6 +704,42 @@ int pt_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t iters, float
     }
     hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, 0ull);
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_build_bvh(pt_ctx* c, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out, int32_t node_capacity, int32_t* n_nodes,
+                 float* build_ms) {
+    if (!c || n_tri < 0 || (n_tri && (!triangles_in || !triangles_out)) || !nodes_out || !n_nodes) return PT_E_INVALID_ARG;
+    const int32_t need = n_tri ? 2 * n_tri - 1 : 1;
+    if (node_capacity < need) FAIL(c, PT_E_INVALID_ARG, "pt_build_bvh: room for %d nodes, %d triangles may need %d", node_capacity, n_tri, need);
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    ptbuild::Tri112 *d_in = nullptr, *d_out = nullptr;
+    ptbuild::Node32* d_nodes = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_nodes); };
+#define TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); FAIL(c, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s", #call, hipGetErrorString(_e)); } } while (0)
+    if (n_tri) {
+        TRY(hipMalloc((void**)&d_in, (size_t)n_tri * 112));
+        TRY(hipMalloc((void**)&d_out, (size_t)n_tri * 112));
+        TRY(hipMemcpyAsync(d_in, triangles_in, (size_t)n_tri * 112, hipMemcpyHostToDevice, c->stream));
+    }
+    TRY(hipMalloc((void**)&d_nodes, (size_t)need * 32));
+    hipEvent_t a = getEvent(c), b = getEvent(c);
+    if (a) (void)hipEventRecord(a, c->stream);
+    uint32_t nn = 0, levels = 0;
+    TRY(ptbuild::build(c->stream, d_in, (uint32_t)n_tri, d_nodes, d_out, &nn, &levels));
+    if (b) (void)hipEventRecord(b, c->stream);
+    if (n_tri) TRY(hipMemcpyAsync(triangles_out, d_out, (size_t)n_tri * 112, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipMemcpyAsync(nodes_out, d_nodes, (size_t)nn * 32, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipStreamSynchronize(c->stream));
+#undef TRY
+    if (build_ms) {
+        *build_ms = 0.0f;
+        if (a && b) (void)hipEventElapsedTime(build_ms, a, b);
+    }
+    if (a) c->pool.push_back(a);
+    if (b) c->pool.push_back(b);
+    cleanup();
+    *n_nodes = (int32_t)nn;
     return PT_OK;
 }
 

@@ -1,0 +1,455 @@
+// Binned-SAH BVH construction on the GPU: the same tree, node for node and byte for byte, as
+// PathTracer/Accelerator.cs:113-310 builds on one CPU thread.
+//
+// What makes the parallel result identical:
+//   * every quantity the reference folds over a primitive list is a minimum, a maximum or a count
+//     (Accelerator.cs:282-310, Box.cs:81-88), so atomics in any order give the same bits (floats go
+//     through an order-preserving integer map; bounds carry no negative zeros or NaNs);
+//   * the split decision of a node (Accelerator.cs:188-262) is evaluated by one thread with the
+//     reference's expression order (this file is compiled without contraction);
+//   * the reference's in-place partition leaves the primitives of a node bin by bin, in their previous
+//     order inside a bin: a stable segmented sort on the 3-bit bin number (rocPRIM);
+//   * the tree is built level by level with arbitrary node numbers and renumbered at the end into the
+//     reference's order: a node's two children, then everything below the left child, then everything
+//     below the right child (Accelerator.cs:136-177).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <cstring>
+#include <vector>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
+namespace ptbuild {
+
+#define PTB_BLOCK 256
+#define PTB_NONE 0xFFFFFFFFu
+#define PTB_EPSILON 0.00001f   // Accelerator.cs:10
+#define PTB_LEAF 3             // Accelerator.cs:11
+#define PTB_BINS 8             // Accelerator.cs:12
+
+struct Tri112 { float v[3][8]; int32_t material; int32_t pad[3]; };   // Triangle.cs:7-13 (three 32-byte vertices)
+struct Node32 { float mn[3], mx[3]; int32_t leftFirst, count; };      // Node.cs:5-10
+
+// order-preserving float <-> uint map (no NaNs here)
+__host__ __device__ inline uint32_t fkey(float f) {
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float fval(uint32_t k) {
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+#define PTB_KEY_POS_INF 0xFF800000u   // fkey(+inf)
+#define PTB_KEY_NEG_INF 0x007FFFFFu   // fkey(-inf)
+
+// node under construction (numbered in creation order)
+struct BNode {
+    float mn[3], mx[3];
+    int32_t first, count;
+    int32_t left;        // creation index of the left child (right = left + 1), -1 for a leaf
+    int32_t axis;        // split axis of an interior node
+    uint32_t next_rank;  // rank in the next level's active list, PTB_NONE if it will not be split further
+    uint32_t below;      // nodes below this one
+    uint32_t block;      // final index of its children pair
+    uint32_t index;      // final index of the node
+};
+
+// per active node of the running level
+struct Split {
+    uint32_t node;
+    int32_t axis;
+    uint32_t cmin, cmax;              // centroid range along the axis (keys)
+    float k0, k1;
+    int32_t usable;                   // 0: becomes a leaf (Accelerator.cs:203-204 or :262)
+    uint32_t split_pos;               // first + primitives on the left
+    uint32_t cnt[PTB_BINS];
+    uint32_t bmn[PTB_BINS][3], bmx[PTB_BINS][3];   // bin domains (keys)
+};
+
+struct Counters { uint32_t nodes, next_active, sort_segments, pad; };
+
+// MathF.Max (NaN-propagating IEEE maximum), Vector.cs:28-31
+__device__ inline float mathfMax(float x, float y) {
+    if (x > y || x != x) return x;
+    if (x == y) return (__float_as_uint(x) >> 31) ? y : x;
+    return y;
+}
+// Box.Domain, Box.cs:25-43
+__device__ inline int domainOf(const float* mn, const float* mx) {
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    const float l = mathfMax(mathfMax(dx, dy), dz);
+    if (l == dx) return 0;
+    if (l == dy) return 1;
+    return 2;
+}
+// Box.Area, Box.cs:45-49
+__device__ inline float areaOf(const float* mn, const float* mx) {
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    return 2.0f * (dx * dy + dx * dz + dy * dz);
+}
+
+// Box.FromVertices + Box.Centroid per primitive (Box.cs:95-102, :20-23); root bounds by atomics
+__global__ void __launch_bounds__(PTB_BLOCK) k_prims(const Tri112* tris, uint32_t n, float4* pmin, float4* pmax, float4* cent, uint32_t* order,
+                                                     uint32_t* seg, uint32_t* root_keys) {
+    __shared__ uint32_t s[6];
+    if (threadIdx.x < 3) s[threadIdx.x] = PTB_KEY_POS_INF;
+    else if (threadIdx.x < 6) s[threadIdx.x] = PTB_KEY_NEG_INF;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const Tri112& t = tris[i];
+        float mn[3], mx[3];
+        for (int a = 0; a < 3; a++) {
+            const float x = t.v[0][a], y = t.v[1][a], z = t.v[2][a];
+            float m = x > y ? x : y;
+            mx[a] = (m > z ? m : z) + 0.00001f;
+            m = x < y ? x : y;
+            mn[a] = (m < z ? m : z) - 0.00001f;
+        }
+        pmin[i] = make_float4(mn[0], mn[1], mn[2], 0.0f);
+        pmax[i] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+        cent[i] = make_float4(0.5f * mn[0] + 0.5f * mx[0], 0.5f * mn[1] + 0.5f * mx[1], 0.5f * mn[2] + 0.5f * mx[2], 0.0f);
+        order[i] = i;
+        seg[i] = 0u;
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&s[a], fkey(mn[a]));
+            atomicMax(&s[3 + a], fkey(mx[a]));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&root_keys[threadIdx.x], s[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&root_keys[threadIdx.x], s[threadIdx.x]);
+}
+
+__global__ void k_root(BNode* nodes, const uint32_t* root_keys, uint32_t n, Counters* ctr, uint32_t* active) {
+    BNode r{};
+    for (int a = 0; a < 3; a++) {
+        r.mn[a] = n ? fval(root_keys[a]) : __builtin_huge_valf();       // Box.Negative, Box.cs:14-18
+        r.mx[a] = n ? fval(root_keys[3 + a]) : -__builtin_huge_valf();
+    }
+    r.first = 0;
+    r.count = (int32_t)n;
+    r.left = -1;
+    r.next_rank = n >= PTB_LEAF ? 0u : PTB_NONE;
+    nodes[0] = r;
+    ctr->nodes = 1;
+    ctr->next_active = n >= PTB_LEAF ? 1u : 0u;
+    ctr->sort_segments = 0;
+    active[0] = 0;
+}
+
+// per active node: split axis, empty centroid range
+__global__ void __launch_bounds__(PTB_BLOCK) k_split_begin(const BNode* nodes, const uint32_t* active, uint32_t n_active, Split* sp) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_active) return;
+    const BNode& nd = nodes[active[r]];
+    Split& s = sp[r];
+    s.node = active[r];
+    s.axis = domainOf(nd.mn, nd.mx);
+    s.cmin = PTB_KEY_POS_INF;
+    s.cmax = PTB_KEY_NEG_INF;
+}
+
+__device__ inline float axisOf(float4 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+// Accelerator.CentroidBounds along the split axis, Accelerator.cs:294-310
+__global__ void __launch_bounds__(PTB_BLOCK) k_centroid_range(const float4* cent, const uint32_t* order, const uint32_t* seg, uint32_t n, Split* sp) {
+    __shared__ uint32_t s_min, s_max, s_rank;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x == 0) {
+        s_min = PTB_KEY_POS_INF;
+        s_max = PTB_KEY_NEG_INF;
+        s_rank = seg[blockIdx.x * blockDim.x];   // the block's first position is always inside the array
+    }
+    __syncthreads();
+    const uint32_t r = i < n ? seg[i] : PTB_NONE;
+    if (r != PTB_NONE) {
+        const uint32_t k = fkey(axisOf(cent[order[i]], sp[r].axis));
+        if (r == s_rank) { atomicMin(&s_min, k); atomicMax(&s_max, k); }
+        else { atomicMin(&sp[r].cmin, k); atomicMax(&sp[r].cmax, k); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rank != PTB_NONE && s_min != PTB_KEY_POS_INF) {
+        atomicMin(&sp[s_rank].cmin, s_min);
+        atomicMax(&sp[s_rank].cmax, s_max);
+    }
+}
+
+// Accelerator.cs:196-213: k0, k1, empty bins
+__global__ void __launch_bounds__(PTB_BLOCK) k_split_bins(uint32_t n_active, Split* sp) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_active) return;
+    Split& s = sp[r];
+    const float k0 = fval(s.cmin);
+    const float l = fval(s.cmax) - k0;
+    s.k0 = k0;
+    s.usable = l < PTB_EPSILON ? 0 : 1;
+    s.k1 = ((float)PTB_BINS - PTB_EPSILON) / l;
+    for (int j = 0; j < PTB_BINS; j++) {
+        s.cnt[j] = 0;
+        for (int a = 0; a < 3; a++) { s.bmn[j][a] = PTB_KEY_POS_INF; s.bmx[j][a] = PTB_KEY_NEG_INF; }
+    }
+}
+
+// Accelerator.cs:215-227: bin of every primitive, bin counts and domains
+__global__ void __launch_bounds__(PTB_BLOCK) k_bin(const float4* cent, const float4* pmin, const float4* pmax, const uint32_t* order, const uint32_t* seg,
+                                                   uint32_t n, Split* sp, uint8_t* bin_of) {
+    __shared__ uint32_t s_cnt[PTB_BINS], s_mn[PTB_BINS][3], s_mx[PTB_BINS][3], s_rank;
+    if (threadIdx.x < PTB_BINS) {
+        s_cnt[threadIdx.x] = 0;
+        for (int a = 0; a < 3; a++) { s_mn[threadIdx.x][a] = PTB_KEY_POS_INF; s_mx[threadIdx.x][a] = PTB_KEY_NEG_INF; }
+    }
+    if (threadIdx.x == 0) s_rank = seg[blockIdx.x * blockDim.x];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = i < n ? seg[i] : PTB_NONE;
+    if (r != PTB_NONE && sp[r].usable) {
+        const Split& s = sp[r];
+        const uint32_t id = order[i];
+        const float c = axisOf(cent[id], s.axis);
+        const float b = (c - s.k0) * s.k1;
+        const int j = (int)b;
+        bin_of[i] = (uint8_t)j;
+        const float4 lo = pmin[id], hi = pmax[id];
+        const uint32_t klo[3] = {fkey(lo.x), fkey(lo.y), fkey(lo.z)}, khi[3] = {fkey(hi.x), fkey(hi.y), fkey(hi.z)};
+        if (r == s_rank) {
+            atomicAdd(&s_cnt[j], 1u);
+            for (int a = 0; a < 3; a++) { atomicMin(&s_mn[j][a], klo[a]); atomicMax(&s_mx[j][a], khi[a]); }
+        } else {
+            Split& g = sp[r];
+            atomicAdd(&g.cnt[j], 1u);
+            for (int a = 0; a < 3; a++) { atomicMin(&g.bmn[j][a], klo[a]); atomicMax(&g.bmx[j][a], khi[a]); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < PTB_BINS && s_rank != PTB_NONE && s_cnt[threadIdx.x] != 0) {
+        Split& g = sp[s_rank];
+        const int j = threadIdx.x;
+        atomicAdd(&g.cnt[j], s_cnt[j]);
+        for (int a = 0; a < 3; a++) { atomicMin(&g.bmn[j][a], s_mn[j][a]); atomicMax(&g.bmx[j][a], s_mx[j][a]); }
+    }
+}
+
+// Box.Union(a, b) with a = a bin's domain, b = the running box (Box.cs:81-88)
+__device__ inline void unionInto(float* mn, float* mx, const uint32_t* kmn, const uint32_t* kmx) {
+    for (int a = 0; a < 3; a++) {
+        const float lo = fval(kmn[a]), hi = fval(kmx[a]);
+        mx[a] = hi > mx[a] ? hi : mx[a];
+        mn[a] = lo < mn[a] ? lo : mn[a];
+    }
+}
+
+// Accelerator.cs:229-262 (the sweep over the 7 split planes) and Accelerator.cs:150-176 (the two children)
+__global__ void __launch_bounds__(PTB_BLOCK) k_split_decide(BNode* nodes, uint32_t n_active, Split* sp, Counters* ctr, uint32_t* next_active,
+                                                            uint32_t* sort_begin, uint32_t* sort_end) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_active) return;
+    Split& s = sp[r];
+    BNode& nd = nodes[s.node];
+    if (!s.usable) return;
+    const float inf = __builtin_huge_valf();
+    const int count = nd.count;
+    int best = -1, bestPlane = 0;
+    float cost = areaOf(nd.mn, nd.mx) * (float)count;
+    int ln = 0, rn = count;
+    float lmn[3] = {inf, inf, inf}, lmx[3] = {-inf, -inf, -inf};
+    for (int i = 1; i < PTB_BINS; i++) {
+        ln += (int)s.cnt[i - 1];
+        rn -= (int)s.cnt[i - 1];
+        unionInto(lmn, lmx, s.bmn[i - 1], s.bmx[i - 1]);
+        float rmn[3] = {inf, inf, inf}, rmx[3] = {-inf, -inf, -inf};
+        for (int j = i; j < PTB_BINS; j++) unionInto(rmn, rmx, s.bmn[j], s.bmx[j]);
+        const float c = (float)ln * areaOf(lmn, lmx) + (float)rn * areaOf(rmn, rmx);
+        if (c < cost) {
+            best = ln;
+            bestPlane = i;
+            cost = c;
+        }
+    }
+    if (best < 0) { s.usable = 0; return; }
+    // children: bounds of the primitives on each side (Accelerator.cs:264-279) = union of their bins' domains
+    BNode L{}, R{};
+    for (int a = 0; a < 3; a++) { L.mn[a] = inf; L.mx[a] = -inf; R.mn[a] = inf; R.mx[a] = -inf; }
+    for (int j = 0; j < PTB_BINS; j++) {
+        if (s.cnt[j] == 0) continue;
+        if (j < bestPlane) unionInto(L.mn, L.mx, s.bmn[j], s.bmx[j]);
+        else unionInto(R.mn, R.mx, s.bmn[j], s.bmx[j]);
+    }
+    L.first = nd.first;
+    L.count = best;
+    R.first = nd.first + best;
+    R.count = count - best;
+    L.left = R.left = -1;
+    L.next_rank = L.count >= PTB_LEAF ? atomicAdd(&ctr->next_active, 1u) : PTB_NONE;
+    R.next_rank = R.count >= PTB_LEAF ? atomicAdd(&ctr->next_active, 1u) : PTB_NONE;
+    const uint32_t at = atomicAdd(&ctr->nodes, 2u);
+    nodes[at] = L;
+    nodes[at + 1] = R;
+    if (L.next_rank != PTB_NONE) next_active[L.next_rank] = at;
+    if (R.next_rank != PTB_NONE) next_active[R.next_rank] = at + 1;
+    nd.left = (int32_t)at;
+    nd.axis = s.axis;
+    s.split_pos = (uint32_t)(nd.first + best);
+    const uint32_t k = atomicAdd(&ctr->sort_segments, 1u);
+    sort_begin[k] = (uint32_t)nd.first;
+    sort_end[k] = (uint32_t)(nd.first + count);
+}
+
+// after the partition: which active node of the next level a position belongs to
+__global__ void __launch_bounds__(PTB_BLOCK) k_reassign(const BNode* nodes, const Split* sp, uint32_t* seg, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = seg[i];
+    if (r == PTB_NONE) return;
+    const Split& s = sp[r];
+    uint32_t next = PTB_NONE;
+    if (s.usable) {
+        const BNode& nd = nodes[s.node];
+        next = nodes[nd.left + (i >= s.split_pos ? 1 : 0)].next_rank;
+    }
+    seg[i] = next;
+}
+
+// ---- renumbering into the reference's order
+__global__ void __launch_bounds__(PTB_BLOCK) k_below(BNode* nodes, uint32_t lo, uint32_t hi) {
+    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    BNode& nd = nodes[i];
+    nd.below = nd.left < 0 ? 0u : 2u + nodes[nd.left].below + nodes[nd.left + 1].below;
+}
+__global__ void __launch_bounds__(PTB_BLOCK) k_number(BNode* nodes, uint32_t lo, uint32_t hi) {
+    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    BNode& nd = nodes[i];
+    if (i == 0) { nd.index = 0; nd.block = 1; }
+    if (nd.left < 0) return;
+    BNode& L = nodes[nd.left];
+    BNode& R = nodes[nd.left + 1];
+    L.index = nd.block;
+    R.index = nd.block + 1;
+    L.block = nd.block + 2;
+    R.block = nd.block + 2 + L.below;
+}
+__global__ void __launch_bounds__(PTB_BLOCK) k_emit(const BNode* nodes, uint32_t n_nodes, Node32* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const BNode& nd = nodes[i];
+    Node32 o;
+    for (int a = 0; a < 3; a++) { o.mn[a] = nd.mn[a]; o.mx[a] = nd.mx[a]; }
+    if (nd.left < 0) { o.leftFirst = nd.first; o.count = nd.count; }
+    else { o.leftFirst = (int32_t)nd.block; o.count = nd.axis * -1 - 1; }   // split axis through a negative count, Accelerator.cs:158-159
+    out[nd.index] = o;
+}
+__global__ void __launch_bounds__(PTB_BLOCK) k_gather(const Tri112* in, const uint32_t* order, uint32_t n, Tri112* out) {
+    // Accelerator.cs:129-133; 7 lanes of 16 bytes per triangle
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = t / 7u, part = t % 7u;
+    if (i >= n) return;
+    ((float4*)(out + i))[part] = ((const float4*)(in + order[i]))[part];
+}
+
+inline int grid(uint32_t n) { return (int)((n + PTB_BLOCK - 1) / PTB_BLOCK); }
+
+// Builds on `stream`.  d_tris: n triangles in insertion order.  On return d_nodes_out (capacity max(1, 2n-1)) and
+// d_tris_out (n) hold the reference's arrays.  Returns hipSuccess or the failing call's error.
+inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, Node32* d_nodes_out, Tri112* d_tris_out, uint32_t* n_nodes_out,
+                        uint32_t* levels_out) {
+#define PTB_TRY(x) do { err = (x); if (err != hipSuccess) goto done; } while (0)
+    hipError_t err = hipSuccess;
+    const uint32_t maxNodes = n ? 2u * n - 1u : 1u;
+    const uint32_t maxActive = n / PTB_LEAF + 2u;
+    float4 *pmin = nullptr, *pmax = nullptr, *cent = nullptr;
+    uint32_t *order[2] = {nullptr, nullptr}, *seg = nullptr, *active[2] = {nullptr, nullptr}, *sortb = nullptr, *sorte = nullptr, *rootk = nullptr;
+    uint8_t* bins[2] = {nullptr, nullptr};
+    BNode* nodes = nullptr;
+    Split* sp = nullptr;
+    Counters* ctr = nullptr;
+    void* tmp = nullptr;
+    size_t tmpBytes = 0;
+    std::vector<uint32_t> levelStart;
+    Counters h{};
+    const uint32_t nn = n ? n : 1u;
+    int cur = 0, act = 0;
+    uint32_t nActive = 0;
+    const uint32_t initKeys[6] = {PTB_KEY_POS_INF, PTB_KEY_POS_INF, PTB_KEY_POS_INF, PTB_KEY_NEG_INF, PTB_KEY_NEG_INF, PTB_KEY_NEG_INF};
+
+    PTB_TRY(hipMalloc((void**)&pmin, (size_t)nn * 16));
+    PTB_TRY(hipMalloc((void**)&pmax, (size_t)nn * 16));
+    PTB_TRY(hipMalloc((void**)&cent, (size_t)nn * 16));
+    for (int k = 0; k < 2; k++) {
+        PTB_TRY(hipMalloc((void**)&order[k], (size_t)nn * 4));
+        PTB_TRY(hipMalloc((void**)&bins[k], (size_t)nn));
+        PTB_TRY(hipMalloc((void**)&active[k], (size_t)maxActive * 4));
+    }
+    PTB_TRY(hipMalloc((void**)&seg, ((size_t)nn + PTB_BLOCK) * 4));
+    PTB_TRY(hipMalloc((void**)&sortb, (size_t)maxActive * 4));
+    PTB_TRY(hipMalloc((void**)&sorte, (size_t)maxActive * 4));
+    PTB_TRY(hipMalloc((void**)&rootk, 6 * 4));
+    PTB_TRY(hipMalloc((void**)&nodes, (size_t)maxNodes * sizeof(BNode)));
+    PTB_TRY(hipMalloc((void**)&sp, (size_t)maxActive * sizeof(Split)));
+    PTB_TRY(hipMalloc((void**)&ctr, sizeof(Counters)));
+    PTB_TRY(hipMemcpyAsync(rootk, initKeys, sizeof(initKeys), hipMemcpyHostToDevice, stream));
+    PTB_TRY(hipMemsetAsync(seg, 0xFF, ((size_t)nn + PTB_BLOCK) * 4, stream));
+    PTB_TRY(hipMemsetAsync(bins[0], 0, nn, stream));
+    if (n) hipLaunchKernelGGL(k_prims, dim3(grid(n)), dim3(PTB_BLOCK), 0, stream, d_tris, n, pmin, pmax, cent, order[0], seg, rootk);
+    hipLaunchKernelGGL(k_root, dim3(1), dim3(1), 0, stream, nodes, rootk, n, ctr, active[0]);
+    PTB_TRY(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
+    PTB_TRY(hipStreamSynchronize(stream));
+    levelStart.push_back(0);
+    levelStart.push_back(h.nodes);
+    nActive = h.next_active;
+    if (n) {
+        // temporary storage of the segmented sort, sized for the worst case once
+        PTB_TRY(rocprim::segmented_radix_sort_pairs(nullptr, tmpBytes, bins[0], bins[1], order[0], order[1], n, maxActive, sortb, sorte, 0, 3, stream));
+        PTB_TRY(hipMalloc(&tmp, tmpBytes ? tmpBytes : 16));
+    }
+    while (nActive > 0) {
+        Counters z{h.nodes, 0u, 0u, 0u};
+        PTB_TRY(hipMemcpyAsync(ctr, &z, sizeof(z), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_split_begin, dim3(grid(nActive)), dim3(PTB_BLOCK), 0, stream, nodes, active[act], nActive, sp);
+        hipLaunchKernelGGL(k_centroid_range, dim3(grid(n)), dim3(PTB_BLOCK), 0, stream, cent, order[cur], seg, n, sp);
+        hipLaunchKernelGGL(k_split_bins, dim3(grid(nActive)), dim3(PTB_BLOCK), 0, stream, nActive, sp);
+        hipLaunchKernelGGL(k_bin, dim3(grid(n)), dim3(PTB_BLOCK), 0, stream, cent, pmin, pmax, order[cur], seg, n, sp, bins[cur]);
+        hipLaunchKernelGGL(k_split_decide, dim3(grid(nActive)), dim3(PTB_BLOCK), 0, stream, nodes, nActive, sp, ctr, active[act ^ 1], sortb, sorte);
+        PTB_TRY(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
+        PTB_TRY(hipStreamSynchronize(stream));
+        if (h.sort_segments > 0) {
+            // positions outside the sorted segments keep their primitive
+            PTB_TRY(hipMemcpyAsync(order[cur ^ 1], order[cur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+            PTB_TRY(rocprim::segmented_radix_sort_pairs(tmp, tmpBytes, bins[cur], bins[cur ^ 1], order[cur], order[cur ^ 1], n, h.sort_segments, sortb, sorte,
+                                                        0, 3, stream));
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL(k_reassign, dim3(grid(n)), dim3(PTB_BLOCK), 0, stream, nodes, sp, seg, n);
+        levelStart.push_back(h.nodes);
+        nActive = h.next_active;
+        act ^= 1;
+    }
+    // renumber: nodes below (deepest level first), then final indices (root first)
+    for (size_t l = levelStart.size() - 1; l-- > 0;) {
+        const uint32_t lo = levelStart[l], hi = levelStart[l + 1];
+        if (hi > lo) hipLaunchKernelGGL(k_below, dim3(grid(hi - lo)), dim3(PTB_BLOCK), 0, stream, nodes, lo, hi);
+    }
+    for (size_t l = 0; l + 1 < levelStart.size(); l++) {
+        const uint32_t lo = levelStart[l], hi = levelStart[l + 1];
+        if (hi > lo) hipLaunchKernelGGL(k_number, dim3(grid(hi - lo)), dim3(PTB_BLOCK), 0, stream, nodes, lo, hi);
+    }
+    hipLaunchKernelGGL(k_emit, dim3(grid(h.nodes)), dim3(PTB_BLOCK), 0, stream, nodes, h.nodes, d_nodes_out);
+    if (n) hipLaunchKernelGGL(k_gather, dim3(grid(n * 7u)), dim3(PTB_BLOCK), 0, stream, d_tris, order[cur], n, d_tris_out);
+    PTB_TRY(hipGetLastError());
+    PTB_TRY(hipStreamSynchronize(stream));
+    *n_nodes_out = h.nodes;
+    if (levels_out) *levels_out = (uint32_t)levelStart.size() - 1u;
+done:
+    (void)hipFree(pmin); (void)hipFree(pmax); (void)hipFree(cent);
+    for (int k = 0; k < 2; k++) { (void)hipFree(order[k]); (void)hipFree(bins[k]); (void)hipFree(active[k]); }
+    (void)hipFree(seg); (void)hipFree(sortb); (void)hipFree(sorte); (void)hipFree(rootk); (void)hipFree(nodes); (void)hipFree(sp); (void)hipFree(ctr); (void)hipFree(tmp);
+    return err;
+#undef PTB_TRY
+}
+
+}  // namespace ptbuild

@@ -125,6 +125,17 @@ class Wavefront:
         self._check(self._lib.pt_bench_extend(self._h, _ptr(rays), n, iters, C.byref(ms), _ptr(tri), _ptr(t)))
         return ms.value, dict(tri=tri, t=t)
 
+    def build_bvh(self, triangles):
+        """Accelerator.Build on the GPU: (Triangle[] reordered, Node[], device milliseconds) for triangles in insertion order."""
+        from .types import NODE, TRIANGLE
+        tris = np.ascontiguousarray(triangles, TRIANGLE)
+        n = tris.size
+        cap = max(1, 2 * n - 1)
+        out_t, out_n = np.zeros(n, TRIANGLE), np.zeros(cap, NODE)
+        nn, ms = C.c_int32(), C.c_float()
+        self._check(self._lib.pt_build_bvh(self._h, _ptr(tris), n, _ptr(out_t), _ptr(out_n), cap, C.byref(nn), C.byref(ms)))
+        return out_t, out_n[:nn.value].copy(), ms.value
+
     def stats(self):
         s = _native.pt_stats()
         self._check(self._lib.pt_get_stats(self._h, C.byref(s)))

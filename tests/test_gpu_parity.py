@@ -54,7 +54,7 @@ def test_generate_bit_exact(pa, ob, bundled, wf_bundled):
 
 
 def test_primary_hit_ids_bit_exact_bundled_512(ob, bundled, wf_bundled):
-    """BASELINE config 1: bundled scene, 512x512 primary rays; ids/t vs the literal C# traversal."""
+    """The reference's own setting: bundled scene, 512x512 primary rays; ids/t vs the literal C# traversal."""
     w = h = 512
     fs = bundled_view(bundled, w, h, frames=1)
     rays, pix = ob.generate(ob.render_state(w, h), fs, ob.path_config(), w * h)
@@ -141,6 +141,45 @@ def test_special_rays_in_the_extend_stage(ob, bundled, wf_bundled):
     assert np.array_equal(tri, can["tri"]) and np.array_equal(bits(t), bits(can["t"]))
     assert np.array_equal(bits(t), bits(lit["t"]))
     assert special.sum() > 1000 and (tri >= 0).sum() > 1000
+
+
+def _host_build(pa, tris, threads=4):
+    from pathtracer_amd.host import Scene
+    s = Scene("")
+    s.add_triangles(tris)
+    s.build(threads)
+    _, t, n = s.arrays()
+    return t, n
+
+
+def test_gpu_bvh_build_is_byte_identical(pa, bundled, soup50k):
+    """pt_build_bvh against the oracle's literal Accelerator.Build (insertion-order references in, same Node[] and
+    Triangle[] bytes out) and, on further inputs, against the host mirror of the same build."""
+    wf = pa.Wavefront()
+    rng = np.random.default_rng(3)
+    for scene in (bundled, soup50k):
+        _, want_t, want_n, refs = scene.arrays(references=True)
+        got_t, got_n, _ = wf.build_bvh(refs)
+        assert got_n.tobytes() == want_n.tobytes() and got_t.tobytes() == want_t.tobytes()
+    bt = bundled.arrays()[1]
+    cases = {"bundled shuffled": bt[rng.permutation(bt.size)], "two": bt[:2], "three": bt[:3], "seven": bt[100:107]}
+    # degenerate inputs: identical triangles (no centroid spread: Accelerator.cs:203-204), and a row of equal boxes
+    same = np.repeat(bt[5:6], 40)
+    cases["identical"] = same
+    row = np.repeat(bt[5:6], 64)
+    for k in range(64):
+        for v in ("v1", "v2", "v3"):
+            row[v]["position"][k, 0] += np.float32(k // 8)       # eight clusters of eight identical triangles
+    cases["clusters"] = row
+    for name, tris in cases.items():
+        want_t, want_n = _host_build(pa, tris)
+        got_t, got_n, ms = wf.build_bvh(tris)
+        assert got_n.size == want_n.size, name
+        assert got_n.tobytes() == want_n.tobytes(), name
+        assert got_t.tobytes() == want_t.tobytes(), name
+    t0, n0, _ = wf.build_bvh(bt[:0])
+    assert t0.size == 0 and n0.size == 1 and n0["count"][0] == 0
+    wf.close()
 
 
 def test_tiny_and_empty_scenes(pa, ob):

@@ -82,7 +82,7 @@ def test_host_meshes_materials_floor(host, ob):
 
 
 def test_host_synthetic_large_scene_generators(host):
-    """The stand-ins for the larger BASELINE scenes: bundled recipe + extra bunnies, and instanced bunnies.  Their BVHs
+    """The stand-ins for the larger benchmark scenes (Sponza- and San-Miguel-sized): bundled recipe + extra bunnies, and instanced bunnies.  Their BVHs
     obey the builder's invariants and are independent of the thread count."""
     s = host.Scene()
     s.initialize_scene_extended(11, 19)
