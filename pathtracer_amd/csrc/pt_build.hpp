@@ -8,7 +8,10 @@
 //   * the split decision of a node (Accelerator.cs:188-262) is evaluated by one thread with the
 //     reference's expression order (this file is compiled without contraction);
 //   * the reference's in-place partition leaves the primitives of a node bin by bin, in their previous
-//     order inside a bin: a stable segmented sort on the 3-bit bin number (rocPRIM);
+//     order inside a bin: a stable sort of the node's range on the 3-bit bin number — rocPRIM's
+//     segmented radix sort for the many small nodes, and for nodes of PTB_CHUNK primitives or more a
+//     chunked counting sort (count per chunk, scan the chunk counts per node, scatter with stable
+//     ranks from wave ballots) that keeps every CU busy on the few huge nodes at the top of the tree;
 //   * the tree is built level by level with arbitrary node numbers and renumbered at the end into the
 //     reference's order: a node's two children, then everything below the left child, then everything
 //     below the right child (Accelerator.cs:136-177).
@@ -27,6 +30,7 @@ namespace ptbuild {
 #define PTB_EPSILON 0.00001f   // Accelerator.cs:10
 #define PTB_LEAF 3             // Accelerator.cs:11
 #define PTB_BINS 8             // Accelerator.cs:12
+#define PTB_CHUNK 2048         // primitives per block of the chunked partition; nodes at least this large take it
 
 struct Tri112 { float v[3][8]; int32_t material; int32_t pad[3]; };   // Triangle.cs:7-13 (three 32-byte vertices)
 struct Node32 { float mn[3], mx[3]; int32_t leftFirst, count; };      // Node.cs:5-10
@@ -66,11 +70,12 @@ struct Split {
     float k0, k1;
     int32_t usable;                   // 0: becomes a leaf (Accelerator.cs:203-204 or :262)
     uint32_t split_pos;               // first + primitives on the left
+    uint32_t chunk_base, chunks;      // its chunks in the level's chunk list (chunks == 0: sorted by the segmented sort)
     uint32_t cnt[PTB_BINS];
     uint32_t bmn[PTB_BINS][3], bmx[PTB_BINS][3];   // bin domains (keys)
 };
 
-struct Counters { uint32_t nodes, next_active, sort_segments, pad; };
+struct Counters { uint32_t nodes, next_active, sort_segments, large, chunks, pad[3]; };
 
 // MathF.Max (NaN-propagating IEEE maximum), Vector.cs:28-31
 __device__ inline float mathfMax(float x, float y) {
@@ -245,7 +250,7 @@ __device__ inline void unionInto(float* mn, float* mx, const uint32_t* kmn, cons
 
 // Accelerator.cs:229-262 (the sweep over the 7 split planes) and Accelerator.cs:150-176 (the two children)
 __global__ void __launch_bounds__(PTB_BLOCK) k_split_decide(BNode* nodes, uint32_t n_active, Split* sp, Counters* ctr, uint32_t* next_active,
-                                                            uint32_t* sort_begin, uint32_t* sort_end) {
+                                                            uint32_t* sort_begin, uint32_t* sort_end, uint32_t* large_rank, uint32_t* chunk_owner) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_active) return;
     Split& s = sp[r];
@@ -294,13 +299,103 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_split_decide(BNode* nodes, uint32
     nd.left = (int32_t)at;
     nd.axis = s.axis;
     s.split_pos = (uint32_t)(nd.first + best);
-    const uint32_t k = atomicAdd(&ctr->sort_segments, 1u);
-    sort_begin[k] = (uint32_t)nd.first;
-    sort_end[k] = (uint32_t)(nd.first + count);
+    s.chunks = 0;
+    if (count >= PTB_CHUNK) {
+        s.chunks = ((uint32_t)count + PTB_CHUNK - 1u) / PTB_CHUNK;
+        s.chunk_base = atomicAdd(&ctr->chunks, s.chunks);
+        large_rank[atomicAdd(&ctr->large, 1u)] = r;
+        for (uint32_t k = 0; k < s.chunks; k++) chunk_owner[s.chunk_base + k] = r;
+    } else {
+        const uint32_t k = atomicAdd(&ctr->sort_segments, 1u);
+        sort_begin[k] = (uint32_t)nd.first;
+        sort_end[k] = (uint32_t)(nd.first + count);
+    }
 }
 
-// after the partition: which active node of the next level a position belongs to
-__global__ void __launch_bounds__(PTB_BLOCK) k_reassign(const BNode* nodes, const Split* sp, uint32_t* seg, uint32_t n) {
+// ---- chunked stable partition of the large nodes
+// pass 1: bin histogram of every chunk
+__global__ void __launch_bounds__(PTB_BLOCK) k_chunk_count(const BNode* nodes, const Split* sp, const uint32_t* chunk_owner, const uint8_t* bin_of, uint32_t* chunk_cnt) {
+    __shared__ uint32_t s_cnt[PTB_BINS];
+    if (threadIdx.x < PTB_BINS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const Split& s = sp[chunk_owner[blockIdx.x]];
+    const BNode& nd = nodes[s.node];
+    const uint32_t lo = (uint32_t)nd.first + (blockIdx.x - s.chunk_base) * PTB_CHUNK;
+    const uint32_t end = (uint32_t)(nd.first + nd.count);
+    const uint32_t hi = lo + PTB_CHUNK < end ? lo + PTB_CHUNK : end;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += PTB_BLOCK) atomicAdd(&s_cnt[bin_of[i]], 1u);
+    __syncthreads();
+    if (threadIdx.x < PTB_BINS) chunk_cnt[blockIdx.x * PTB_BINS + threadIdx.x] = s_cnt[threadIdx.x];
+}
+
+__device__ inline uint32_t waveScanInclusive(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const uint32_t row = (threadIdx.x & 63u) >> 4;
+    return v + (row > 0u ? r0 : 0u) + (row > 1u ? r1 : 0u) + (row > 2u ? r2 : 0u);
+}
+
+// pass 2: one block per large node; wave w scans bins 2w and 2w+1 over the node's chunks: chunk_cnt becomes the
+// destination of the chunk's first primitive of that bin
+__global__ void __launch_bounds__(PTB_BLOCK) k_chunk_scan(const BNode* nodes, const Split* sp, const uint32_t* large_rank, uint32_t* chunk_cnt) {
+    const Split& s = sp[large_rank[blockIdx.x]];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t b = wave * 2u; b < wave * 2u + 2u; b++) {
+        uint32_t run = (uint32_t)nodes[s.node].first;
+        for (uint32_t j = 0; j < b; j++) run += s.cnt[j];
+        for (uint32_t k0 = 0; k0 < s.chunks; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            const uint32_t c = k < s.chunks ? chunk_cnt[(s.chunk_base + k) * PTB_BINS + b] : 0u;
+            const uint32_t incl = waveScanInclusive(c);
+            if (k < s.chunks) chunk_cnt[(s.chunk_base + k) * PTB_BINS + b] = run + incl - c;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+}
+
+// pass 3: scatter; the rank of a primitive among the earlier ones of its bin comes from wave ballots
+__global__ void __launch_bounds__(PTB_BLOCK) k_chunk_scatter(const BNode* nodes, const Split* sp, const uint32_t* chunk_owner, const uint8_t* bin_of,
+                                                             const uint32_t* chunk_cnt, const uint32_t* order, uint32_t* sorted) {
+    __shared__ uint32_t s_run[PTB_BINS], s_wave[PTB_BLOCK / 64][PTB_BINS];
+    const Split& s = sp[chunk_owner[blockIdx.x]];
+    const BNode& nd = nodes[s.node];
+    const uint32_t lo = (uint32_t)nd.first + (blockIdx.x - s.chunk_base) * PTB_CHUNK;
+    const uint32_t end = (uint32_t)(nd.first + nd.count);
+    const uint32_t hi = lo + PTB_CHUNK < end ? lo + PTB_CHUNK : end;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x < PTB_BINS) s_run[threadIdx.x] = chunk_cnt[blockIdx.x * PTB_BINS + threadIdx.x];
+    for (uint32_t base = lo; base < hi; base += PTB_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t b = i < hi ? bin_of[i] : PTB_BINS;
+        uint32_t mine = 0;
+        for (uint32_t bb = 0; bb < PTB_BINS; bb++) {
+            const unsigned long long m = __ballot(b == bb);
+            if (b == bb) mine = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave[wave][bb] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (b < PTB_BINS) {
+            uint32_t at = s_run[b] + mine;
+            for (uint32_t w = 0; w < wave; w++) at += s_wave[w][b];
+            sorted[at] = order[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < PTB_BINS) {
+            uint32_t add = 0;
+            for (uint32_t w = 0; w < PTB_BLOCK / 64; w++) add += s_wave[w][threadIdx.x];
+            s_run[threadIdx.x] += add;
+        }
+        __syncthreads();
+    }
+}
+
+// after the partition: take the sorted primitive of every position whose node was split, and note which active
+// node of the next level the position belongs to
+__global__ void __launch_bounds__(PTB_BLOCK) k_reassign(const BNode* nodes, const Split* sp, uint32_t* seg, uint32_t n, uint32_t* order, const uint32_t* sorted) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = seg[i];
@@ -310,6 +405,7 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_reassign(const BNode* nodes, cons
     if (s.usable) {
         const BNode& nd = nodes[s.node];
         next = nodes[nd.left + (i >= s.split_pos ? 1 : 0)].next_rank;
+        order[i] = sorted[i];
     }
     seg[i] = next;
 }
@@ -364,6 +460,8 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     const uint32_t maxActive = n / PTB_LEAF + 2u;
     float4 *pmin = nullptr, *pmax = nullptr, *cent = nullptr;
     uint32_t *order[2] = {nullptr, nullptr}, *seg = nullptr, *active[2] = {nullptr, nullptr}, *sortb = nullptr, *sorte = nullptr, *rootk = nullptr;
+    uint32_t *largeRank = nullptr, *chunkOwner = nullptr, *chunkCnt = nullptr;
+    const uint32_t maxChunks = 2u * (n / PTB_CHUNK) + 2u, maxLarge = n / PTB_CHUNK + 1u;
     uint8_t* bins[2] = {nullptr, nullptr};
     BNode* nodes = nullptr;
     Split* sp = nullptr;
@@ -373,7 +471,8 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     std::vector<uint32_t> levelStart;
     Counters h{};
     const uint32_t nn = n ? n : 1u;
-    int cur = 0, act = 0;
+    const int cur = 0;
+    int act = 0;
     uint32_t nActive = 0;
     const uint32_t initKeys[6] = {PTB_KEY_POS_INF, PTB_KEY_POS_INF, PTB_KEY_POS_INF, PTB_KEY_NEG_INF, PTB_KEY_NEG_INF, PTB_KEY_NEG_INF};
 
@@ -389,6 +488,9 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     PTB_TRY(hipMalloc((void**)&sortb, (size_t)maxActive * 4));
     PTB_TRY(hipMalloc((void**)&sorte, (size_t)maxActive * 4));
     PTB_TRY(hipMalloc((void**)&rootk, 6 * 4));
+    PTB_TRY(hipMalloc((void**)&largeRank, (size_t)maxLarge * 4));
+    PTB_TRY(hipMalloc((void**)&chunkOwner, (size_t)maxChunks * 4));
+    PTB_TRY(hipMalloc((void**)&chunkCnt, (size_t)maxChunks * PTB_BINS * 4));
     PTB_TRY(hipMalloc((void**)&nodes, (size_t)maxNodes * sizeof(BNode)));
     PTB_TRY(hipMalloc((void**)&sp, (size_t)maxActive * sizeof(Split)));
     PTB_TRY(hipMalloc((void**)&ctr, sizeof(Counters)));
@@ -408,23 +510,24 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
         PTB_TRY(hipMalloc(&tmp, tmpBytes ? tmpBytes : 16));
     }
     while (nActive > 0) {
-        Counters z{h.nodes, 0u, 0u, 0u};
+        Counters z{};
+        z.nodes = h.nodes;
         PTB_TRY(hipMemcpyAsync(ctr, &z, sizeof(z), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(k_split_begin, dim3(grid(nActive)), dim3(PTB_BLOCK), 0, stream, nodes, active[act], nActive, sp);
         hipLaunchKernelGGL(k_centroid_range, dim3(grid(n)), dim3(PTB_BLOCK), 0, stream, cent, order[cur], seg, n, sp);
         hipLaunchKernelGGL(k_split_bins, dim3(grid(nActive)), dim3(PTB_BLOCK), 0, stream, nActive, sp);
         hipLaunchKernelGGL(k_bin, dim3(grid(n)), dim3(PTB_BLOCK), 0, stream, cent, pmin, pmax, order[cur], seg, n, sp, bins[cur]);
-        hipLaunchKernelGGL(k_split_decide, dim3(grid(nActive)), dim3(PTB_BLOCK), 0, stream, nodes, nActive, sp, ctr, active[act ^ 1], sortb, sorte);
+        hipLaunchKernelGGL(k_split_decide, dim3(grid(nActive)), dim3(PTB_BLOCK), 0, stream, nodes, nActive, sp, ctr, active[act ^ 1], sortb, sorte, largeRank, chunkOwner);
         PTB_TRY(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
         PTB_TRY(hipStreamSynchronize(stream));
-        if (h.sort_segments > 0) {
-            // positions outside the sorted segments keep their primitive
-            PTB_TRY(hipMemcpyAsync(order[cur ^ 1], order[cur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
-            PTB_TRY(rocprim::segmented_radix_sort_pairs(tmp, tmpBytes, bins[cur], bins[cur ^ 1], order[cur], order[cur ^ 1], n, h.sort_segments, sortb, sorte,
-                                                        0, 3, stream));
-            cur ^= 1;
+        if (h.sort_segments > 0)   // sorted copies of the split nodes' ranges land in order[1]; k_reassign takes them over
+            PTB_TRY(rocprim::segmented_radix_sort_pairs(tmp, tmpBytes, bins[0], bins[1], order[0], order[1], n, h.sort_segments, sortb, sorte, 0, 3, stream));
+        if (h.chunks > 0) {
+            hipLaunchKernelGGL(k_chunk_count, dim3(h.chunks), dim3(PTB_BLOCK), 0, stream, nodes, sp, chunkOwner, bins[0], chunkCnt);
+            hipLaunchKernelGGL(k_chunk_scan, dim3(h.large), dim3(PTB_BLOCK), 0, stream, nodes, sp, largeRank, chunkCnt);
+            hipLaunchKernelGGL(k_chunk_scatter, dim3(h.chunks), dim3(PTB_BLOCK), 0, stream, nodes, sp, chunkOwner, bins[0], chunkCnt, order[0], order[1]);
         }
-        hipLaunchKernelGGL(k_reassign, dim3(grid(n)), dim3(PTB_BLOCK), 0, stream, nodes, sp, seg, n);
+        hipLaunchKernelGGL(k_reassign, dim3(grid(n)), dim3(PTB_BLOCK), 0, stream, nodes, sp, seg, n, order[0], order[1]);
         levelStart.push_back(h.nodes);
         nActive = h.next_active;
         act ^= 1;
@@ -447,6 +550,7 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
 done:
     (void)hipFree(pmin); (void)hipFree(pmax); (void)hipFree(cent);
     for (int k = 0; k < 2; k++) { (void)hipFree(order[k]); (void)hipFree(bins[k]); (void)hipFree(active[k]); }
+    (void)hipFree(largeRank); (void)hipFree(chunkOwner); (void)hipFree(chunkCnt);
     (void)hipFree(seg); (void)hipFree(sortb); (void)hipFree(sorte); (void)hipFree(rootk); (void)hipFree(nodes); (void)hipFree(sp); (void)hipFree(ctr); (void)hipFree(tmp);
     return err;
 #undef PTB_TRY
