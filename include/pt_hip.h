@@ -138,6 +138,13 @@ int pt_reset_stats(pt_ctx* ctx);
 int pt_build_bvh(pt_ctx* ctx, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out, int32_t node_capacity,
                  int32_t* n_nodes, float* build_ms);
 
+/* Scene.CopyToDevice with the build on the GPU (Scene.cs:176-183 + Accelerator.Build): builds the tree as pt_build_bvh
+ * does and derives the device scene from it without visiting the host — the one call replaces Accelerator.Build +
+ * pt_upload_scene.  materials: Material[n_mat]; triangles_in: Accelerator.AddTriangle order.  triangles_out / nodes_out
+ * (each may be NULL) receive the built arrays for the host's own mirrors; node_capacity as for pt_build_bvh. */
+int pt_build_scene(pt_ctx* ctx, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri, void* triangles_out,
+                   void* nodes_out, int32_t node_capacity, int32_t* n_nodes, float* build_ms);
+
 /* Runtime switches: key is one of PT_OPT_*; takes effect at the next pt_render. */
 enum { PT_OPT_NEE = 1, PT_OPT_RNG_MODE = 2, PT_OPT_TRAVERSAL_STATS = 3, PT_OPT_STAGE_TIMING = 4, PT_OPT_SAMPLES_PER_BATCH = 5,
        PT_OPT_TRAVERSE_BLOCKS_PER_CU = 6 /* resident 256-thread blocks per CU of the traversal kernels; 0 = the default (at most 7) */ };

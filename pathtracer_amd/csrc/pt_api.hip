@@ -5,6 +5,7 @@
 #include "pt_hip.h"
 #include "pt_kernels.hpp"
 #include "pt_build.hpp"
+#include "pt_repack.hpp"
 #include <string>
 #include <vector>
 #include <cstring>
@@ -177,6 +178,21 @@ int validateBvh(pt_ctx* c, const HostNode* nodes, int n_nodes, int n_tris, int* 
 
 int launchGrid(uint32_t n) { return (int)((n + PT_BLOCK - 1) / PT_BLOCK); }
 
+// One row of the light table: (V1, running area sum) (V2, material bits) (V3, 0); areas are summed in triangle order.
+void appendLight(const HostTriangle& t, std::vector<float4>& lights, float& lightSum) {
+    const float* a = t.v[0].pos; const float* b = t.v[1].pos; const float* cc = t.v[2].pos;
+    float mbits;
+    memcpy(&mbits, &t.material, 4);
+    const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    const float e2[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]};
+    const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+    const float area = 0.5f * sqrtf((nx * nx + ny * ny) + nz * nz);
+    lightSum = lightSum + area;
+    lights.push_back(make_float4(a[0], a[1], a[2], lightSum));
+    lights.push_back(make_float4(b[0], b[1], b[2], mbits));
+    lights.push_back(make_float4(cc[0], cc[1], cc[2], 0.0f));
+}
+
 }  // namespace
 
 extern "C" {
@@ -298,14 +314,7 @@ int pt_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void*
         hot[3 * (size_t)i + 2] = make_float4(e2[0], e2[1], e2[2], 0.0f);
         for (int k = 0; k < 3; k++) cold[3 * (size_t)i + k] = make_float4(t.v[k].nrm[0], t.v[k].nrm[1], t.v[k].nrm[2], 0.0f);
         const HostMaterial& m = hm[t.material];
-        if (m.emissive[0] > 0 || m.emissive[1] > 0 || m.emissive[2] > 0) {   // shade.glsl:366
-            const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
-            const float area = 0.5f * sqrtf((nx * nx + ny * ny) + nz * nz);
-            lightSum = lightSum + area;
-            lights.push_back(make_float4(a[0], a[1], a[2], lightSum));
-            lights.push_back(make_float4(b[0], b[1], b[2], mbits));
-            lights.push_back(make_float4(cc[0], cc[1], cc[2], 0.0f));
-        }
+        if (m.emissive[0] > 0 || m.emissive[1] > 0 || m.emissive[2] > 0) appendLight(t, lights, lightSum);   // shade.glsl:366
     }
     auto upload = [&](void** dst, const void* src, size_t bytes) -> int {
         if (bytes == 0) { *dst = nullptr; return PT_OK; }
@@ -740,6 +749,136 @@ int pt_build_bvh(pt_ctx* c, const void* triangles_in, int32_t n_tri, void* trian
     if (b) c->pool.push_back(b);
     cleanup();
     *n_nodes = (int32_t)nn;
+    return PT_OK;
+}
+
+int pt_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out,
+                   int32_t node_capacity, int32_t* n_nodes, float* build_ms) {
+    if (!c || n_mat < 0 || n_tri < 0 || (n_mat && !materials) || (n_tri && !triangles_in)) return PT_E_INVALID_ARG;
+    const int32_t need = n_tri ? 2 * n_tri - 1 : 1;
+    if (nodes_out && node_capacity < need) FAIL(c, PT_E_INVALID_ARG, "pt_build_scene: room for %d nodes, %d triangles may need %d", node_capacity, n_tri, need);
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    freeScene(c);
+    const uint32_t n = (uint32_t)n_tri;
+    ptbuild::Tri112 *d_in = nullptr, *d_sorted = nullptr, *d_lightTris = nullptr;
+    ptbuild::Node32* d_nodes = nullptr;
+    ptbuild::BNode* bn = nullptr;
+    uint32_t *d_flagA = nullptr, *d_idxA = nullptr, *d_flagB = nullptr, *d_idxB = nullptr, *d_bad = nullptr;
+    void* tmp = nullptr;
+    size_t tmpBytes = 0;
+    auto cleanup = [&]() {
+        (void)hipFree(d_in); (void)hipFree(d_sorted); (void)hipFree(d_lightTris); (void)hipFree(d_nodes); (void)hipFree(bn);
+        (void)hipFree(d_flagA); (void)hipFree(d_idxA); (void)hipFree(d_flagB); (void)hipFree(d_idxB); (void)hipFree(d_bad); (void)hipFree(tmp);
+    };
+#define TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); freeScene(c); FAIL(c, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s", #call, hipGetErrorString(_e)); } } while (0)
+    if (n) {
+        TRY(hipMalloc((void**)&d_in, (size_t)n * 112));
+        TRY(hipMalloc((void**)&d_sorted, (size_t)n * 112));
+        TRY(hipMemcpyAsync(d_in, triangles_in, (size_t)n * 112, hipMemcpyHostToDevice, c->stream));
+    }
+    TRY(hipMalloc((void**)&d_nodes, (size_t)need * 32));
+    hipEvent_t ea = getEvent(c), eb = getEvent(c);
+    if (ea) (void)hipEventRecord(ea, c->stream);
+    uint32_t nn = 0, levels = 0;
+    TRY(ptbuild::build(c->stream, d_in, n, d_nodes, d_sorted, &nn, &levels, &bn));
+    (void)hipFree(d_in);
+    d_in = nullptr;
+    if ((int)levels > PT_STACK_TOTAL || 3 * (((int)levels + 1) / 2) > PT_STACK_TOTAL) {
+        cleanup();
+        FAIL(c, PT_E_BAD_BVH, "BVH depth %u exceeds the traversal stack (%d entries)", levels, PT_STACK_TOTAL);
+    }
+    const size_t flagsLen = std::max<size_t>(std::max<size_t>(n, nn), 1);
+    TRY(hipMalloc((void**)&d_flagA, flagsLen * 4));
+    TRY(hipMalloc((void**)&d_idxA, flagsLen * 4));
+    TRY(hipMalloc((void**)&d_flagB, flagsLen * 4));
+    TRY(hipMalloc((void**)&d_idxB, flagsLen * 4));
+    TRY(hipMalloc((void**)&d_bad, 4));
+    TRY(hipMemsetAsync(d_bad, 0, 4, c->stream));
+    if (n_mat) {
+        TRY(hipMalloc(&c->d_mats, (size_t)n_mat * 48));
+        TRY(hipMemcpyAsync(c->d_mats, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, c->stream));
+    }
+    // ---- triangles: hot / cold records, the light table
+    std::vector<float4> lights;
+    float lightSum = 0.0f;
+    if (n) {
+        TRY(hipMalloc(&c->d_hot, (size_t)n * 48));
+        TRY(hipMalloc(&c->d_cold, (size_t)n * 48));
+        hipLaunchKernelGGL(ptrepack::k_triangles, dim3(launchGrid(n)), dim3(256), 0, c->stream, d_sorted, n, (const float4*)c->d_mats, n_mat,
+                           (float4*)c->d_hot, (float4*)c->d_cold, d_flagA, d_bad);
+        TRY(ptrepack::exclusiveScan(c->stream, d_flagA, d_idxA, n, &tmp, &tmpBytes));
+        uint32_t lastFlag = 0, lastIdx = 0, bad = 0;
+        TRY(hipMemcpyAsync(&lastFlag, d_flagA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&lastIdx, d_idxA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipStreamSynchronize(c->stream));
+        if (bad) { cleanup(); freeScene(c); FAIL(c, PT_E_INVALID_ARG, "a triangle has a material index outside [0, %d)", n_mat); }
+        const uint32_t nLights = lastFlag + lastIdx;
+        if (nLights) {
+            TRY(hipMalloc((void**)&d_lightTris, (size_t)nLights * 112));
+            hipLaunchKernelGGL(ptrepack::k_collect_lights, dim3(launchGrid(n)), dim3(256), 0, c->stream, d_sorted, n, d_flagA, d_idxA, d_lightTris);
+            std::vector<HostTriangle> lt(nLights);
+            TRY(hipMemcpyAsync(lt.data(), d_lightTris, (size_t)nLights * 112, hipMemcpyDeviceToHost, c->stream));
+            TRY(hipStreamSynchronize(c->stream));
+            for (const HostTriangle& t : lt) appendLight(t, lights, lightSum);   // triangle order: the running sum rounds as on the CPU path
+            TRY(hipMalloc(&c->d_lights, lights.size() * sizeof(float4)));
+            TRY(hipMemcpyAsync(c->d_lights, lights.data(), lights.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    // ---- nodes: pair records, quad records, big-leaf rows
+    uint32_t nQuads = 0, nBig = 0;
+    {
+        hipLaunchKernelGGL(ptrepack::k_flags, dim3(launchGrid(nn)), dim3(256), 0, c->stream, bn, nn, d_flagA, d_flagB);
+        TRY(ptrepack::exclusiveScan(c->stream, d_flagA, d_idxA, nn, &tmp, &tmpBytes));
+        TRY(ptrepack::exclusiveScan(c->stream, d_flagB, d_idxB, nn, &tmp, &tmpBytes));
+        uint32_t v[4] = {0, 0, 0, 0};
+        TRY(hipMemcpyAsync(&v[0], d_flagA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&v[1], d_idxA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&v[2], d_flagB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&v[3], d_idxB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipStreamSynchronize(c->stream));
+        nQuads = v[0] + v[1];
+        nBig = v[2] + v[3];
+        if (nBig >= PT_LEAF_MAX_FIRST) { cleanup(); freeScene(c); FAIL(c, PT_E_BAD_BVH, "%u leaves of more than %d triangles", nBig, PT_LEAF_MAX_COUNT); }
+        if (nn > 1) TRY(hipMalloc(&c->d_pairs, (size_t)(nn - 1) * 32));
+        if (nQuads) TRY(hipMalloc(&c->d_quads, (size_t)nQuads * 128));
+        if (nBig) TRY(hipMalloc(&c->d_big, (size_t)nBig * 8));
+        hipLaunchKernelGGL(ptrepack::k_records, dim3(launchGrid(nn)), dim3(256), 0, c->stream, bn, nn, d_idxA, d_idxB, d_flagB, (float4*)c->d_pairs,
+                           (float4*)c->d_quads, (uint2*)c->d_big);
+    }
+    ptbuild::BNode root;
+    TRY(hipMemcpyAsync(&root, bn, sizeof(root), hipMemcpyDeviceToHost, c->stream));
+    if (eb) (void)hipEventRecord(eb, c->stream);
+    if (triangles_out && n) TRY(hipMemcpyAsync(triangles_out, d_sorted, (size_t)n * 112, hipMemcpyDeviceToHost, c->stream));
+    if (nodes_out) TRY(hipMemcpyAsync(nodes_out, d_nodes, (size_t)nn * 32, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipGetLastError());
+    TRY(hipStreamSynchronize(c->stream));
+#undef TRY
+    if (build_ms) {
+        *build_ms = 0.0f;
+        if (ea && eb) (void)hipEventElapsedTime(build_ms, ea, eb);
+    }
+    if (ea) c->pool.push_back(ea);
+    if (eb) c->pool.push_back(eb);
+    cleanup();
+    DevScene& sc = c->sc;
+    sc.pairs = (const float4*)c->d_pairs;
+    sc.quads = (const float4*)c->d_quads;
+    sc.big = (const uint2*)c->d_big;
+    sc.tri_hot = (const float4*)c->d_hot;
+    sc.tri_cold = (const float4*)c->d_cold;
+    sc.mats = (const float4*)c->d_mats;
+    sc.lights = (const float4*)c->d_lights;
+    sc.n_nodes = n ? (int32_t)nn : 0;
+    sc.n_tris = n_tri;
+    sc.n_lights = (int32_t)(lights.size() / 3);
+    sc.light_total = lightSum;
+    for (int k = 0; k < 3; k++) { sc.root_min[k] = root.mn[k]; sc.root_max[k] = root.mx[k]; }
+    sc.root_left = root.left >= 0 ? root.left : root.first;
+    sc.root_count = root.left >= 0 ? 0 : root.count;
+    c->has_scene = true;
+    if (n_nodes) *n_nodes = (int32_t)nn;
     return PT_OK;
 }
 

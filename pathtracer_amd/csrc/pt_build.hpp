@@ -60,6 +60,8 @@ struct BNode {
     uint32_t below;      // nodes below this one
     uint32_t block;      // final index of its children pair
     uint32_t index;      // final index of the node
+    uint32_t level;      // depth (root 0)
+    uint32_t aux;        // repack: quad index of an interior node at an even depth / big-leaf row of a large leaf
 };
 
 // per active node of the running level
@@ -139,6 +141,7 @@ __global__ void k_root(BNode* nodes, const uint32_t* root_keys, uint32_t n, Coun
     r.first = 0;
     r.count = (int32_t)n;
     r.left = -1;
+    r.level = 0;
     r.next_rank = n >= PTB_LEAF ? 0u : PTB_NONE;
     nodes[0] = r;
     ctr->nodes = 1;
@@ -289,6 +292,7 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_split_decide(BNode* nodes, uint32
     R.first = nd.first + best;
     R.count = count - best;
     L.left = R.left = -1;
+    L.level = R.level = nd.level + 1u;
     L.next_rank = L.count >= PTB_LEAF ? atomicAdd(&ctr->next_active, 1u) : PTB_NONE;
     R.next_rank = R.count >= PTB_LEAF ? atomicAdd(&ctr->next_active, 1u) : PTB_NONE;
     const uint32_t at = atomicAdd(&ctr->nodes, 2u);
@@ -452,8 +456,9 @@ inline int grid(uint32_t n) { return (int)((n + PTB_BLOCK - 1) / PTB_BLOCK); }
 
 // Builds on `stream`.  d_tris: n triangles in insertion order.  On return d_nodes_out (capacity max(1, 2n-1)) and
 // d_tris_out (n) hold the reference's arrays.  Returns hipSuccess or the failing call's error.
+// keep_nodes (optional): receives the construction-order node array instead of it being freed (hipFree it).
 inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, Node32* d_nodes_out, Tri112* d_tris_out, uint32_t* n_nodes_out,
-                        uint32_t* levels_out) {
+                        uint32_t* levels_out, BNode** keep_nodes = nullptr) {
 #define PTB_TRY(x) do { err = (x); if (err != hipSuccess) goto done; } while (0)
     hipError_t err = hipSuccess;
     const uint32_t maxNodes = n ? 2u * n - 1u : 1u;
@@ -547,6 +552,7 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     PTB_TRY(hipStreamSynchronize(stream));
     *n_nodes_out = h.nodes;
     if (levels_out) *levels_out = (uint32_t)levelStart.size() - 1u;
+    if (keep_nodes) { *keep_nodes = nodes; nodes = nullptr; }
 done:
     (void)hipFree(pmin); (void)hipFree(pmax); (void)hipFree(cent);
     for (int k = 0; k < 2; k++) { (void)hipFree(order[k]); (void)hipFree(bins[k]); (void)hipFree(active[k]); }

@@ -1,0 +1,101 @@
+// The device scene (quad records, pair records, hot/cold triangles) derived on the GPU from a tree that
+// ptbuild::build has just constructed, so a scene built on the device never visits the host.
+// Records are the ones pt_upload_scene forms on the CPU from the host's arrays (see pt_device.hpp: DevScene);
+// node numbers here are construction order (a node's children are adjacent at an odd index, like the host's),
+// which the traversal never observes.
+#pragma once
+#include "pt_build.hpp"
+#include "pt_device.hpp"
+#include <rocprim/device/device_scan.hpp>
+
+namespace ptrepack {
+
+using ptbuild::BNode;
+using ptbuild::Tri112;
+
+__device__ inline bool fitsPacked(int32_t first, int32_t count) { return count <= PT_LEAF_MAX_COUNT && (uint32_t)first < PT_LEAF_MAX_FIRST; }
+
+// hot / cold triangle records (pt_upload_scene does the same two subtractions, Triangle.cs:17-18), emissive flags
+__global__ void __launch_bounds__(256) k_triangles(const Tri112* tris, uint32_t n, const float4* mats, int32_t n_mat, float4* hot, float4* cold,
+                                                   uint32_t* emissive, uint32_t* bad_material) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Tri112& t = tris[i];
+    const float* a = t.v[0]; const float* b = t.v[1]; const float* c = t.v[2];
+    hot[3 * (size_t)i] = make_float4(a[0], a[1], a[2], __int_as_float(t.material));
+    hot[3 * (size_t)i + 1] = make_float4(b[0] - a[0], b[1] - a[1], b[2] - a[2], 0.0f);
+    hot[3 * (size_t)i + 2] = make_float4(c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.0f);
+    for (int k = 0; k < 3; k++) cold[3 * (size_t)i + k] = make_float4(t.v[k][4], t.v[k][5], t.v[k][6], 0.0f);
+    uint32_t e = 0;
+    if (t.material < 0 || t.material >= n_mat) atomicOr(bad_material, 1u);
+    else {
+        const float4 em = mats[3 * (size_t)t.material + 1];   // Material.Emissive, Material.cs:7-28
+        e = (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) ? 1u : 0u;   // shade.glsl:366
+    }
+    emissive[i] = e;
+}
+__global__ void __launch_bounds__(256) k_collect_lights(const Tri112* tris, uint32_t n, const uint32_t* emissive, const uint32_t* slot, Tri112* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && emissive[i]) out[slot[i]] = tris[i];
+}
+
+// which nodes own a quad record (interior, even depth) and which leaves need a big-leaf row
+__global__ void __launch_bounds__(256) k_flags(const BNode* nodes, uint32_t n_nodes, uint32_t* quad_flag, uint32_t* big_flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const BNode& nd = nodes[i];
+    quad_flag[i] = (nd.left >= 0 && (nd.level & 1u) == 0u) ? 1u : 0u;
+    big_flag[i] = (nd.left < 0 && nd.count > 0 && !fitsPacked(nd.first, nd.count)) ? 1u : 0u;
+}
+__device__ inline uint32_t leafEntry(const BNode& nd, uint32_t big_row) {
+    if (fitsPacked(nd.first, nd.count)) return PT_LEAF_FLAG | ((uint32_t)(nd.count - 1) << 27) | (uint32_t)nd.first;
+    return PT_LEAF_FLAG | (15u << 27) | big_row;
+}
+__global__ void __launch_bounds__(256) k_records(const BNode* nodes, uint32_t n_nodes, const uint32_t* quad_idx, const uint32_t* big_idx, const uint32_t* big_flag,
+                                                 float4* pairs, float4* quads, uint2* big) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const BNode& nd = nodes[i];
+    if (big_flag[i]) big[big_idx[i]] = make_uint2((uint32_t)nd.first, (uint32_t)nd.count);
+    if (i > 0) {
+        // half of pair record (i-1)/2: the node's box, its entry, its count word
+        const uint32_t e = nd.left >= 0 ? (uint32_t)nd.left : leafEntry(nd, big_idx[i]);
+        pairs[2 * (size_t)(i - 1)] = make_float4(nd.mn[0], nd.mn[1], nd.mn[2], nd.mx[0]);
+        pairs[2 * (size_t)(i - 1) + 1] = make_float4(nd.mx[1], nd.mx[2], __uint_as_float(e), __int_as_float(nd.left >= 0 ? -nd.axis - 1 : nd.count));
+    }
+    if (nd.left >= 0 && (nd.level & 1u) == 0u) {
+        int32_t kids[4];
+        int nk = 0;
+        for (int32_t ch = nd.left; ch <= nd.left + 1; ch++) {
+            if (nodes[ch].left < 0) kids[nk++] = ch;
+            else { kids[nk++] = nodes[ch].left; kids[nk++] = nodes[ch].left + 1; }
+        }
+        float box[6][4] = {};
+        uint32_t ent[4] = {0, 0, 0, 0};
+        for (int k = 0; k < nk; k++) {
+            const BNode& kd = nodes[kids[k]];
+            for (int a = 0; a < 3; a++) { box[a][k] = kd.mn[a]; box[3 + a][k] = kd.mx[a]; }
+            ent[k] = kd.left >= 0 ? quad_idx[kids[k]] + 1u : leafEntry(kd, big_idx[kids[k]]);
+        }
+        float4* q = quads + 8 * (size_t)quad_idx[i];
+        for (int a = 0; a < 6; a++) q[a] = make_float4(box[a][0], box[a][1], box[a][2], box[a][3]);
+        q[6] = make_float4(__uint_as_float(ent[0]), __uint_as_float(ent[1]), __uint_as_float(ent[2]), __uint_as_float(ent[3]));
+        q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+inline hipError_t exclusiveScan(hipStream_t stream, const uint32_t* in, uint32_t* out, size_t n, void** tmp, size_t* tmpBytes) {
+    size_t need = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, need, in, out, 0u, n, rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) return e;
+    if (need > *tmpBytes) {
+        (void)hipFree(*tmp);
+        *tmp = nullptr;
+        e = hipMalloc(tmp, need);
+        if (e != hipSuccess) return e;
+        *tmpBytes = need;
+    }
+    return rocprim::exclusive_scan(*tmp, need, in, out, 0u, n, rocprim::plus<uint32_t>(), stream);
+}
+
+}  // namespace ptrepack

@@ -136,6 +136,20 @@ class Wavefront:
         self._check(self._lib.pt_build_bvh(self._h, _ptr(tris), n, _ptr(out_t), _ptr(out_n), cap, C.byref(nn), C.byref(ms)))
         return out_t, out_n[:nn.value].copy(), ms.value
 
+    def build_scene(self, materials, triangles, want_arrays=False):
+        """Build the BVH on the GPU and install the scene without a host round trip (pt_build_scene).
+        Returns device milliseconds, or (Triangle[], Node[], ms) with want_arrays."""
+        from .types import MATERIAL, NODE, TRIANGLE
+        mats = np.ascontiguousarray(materials, MATERIAL)
+        tris = np.ascontiguousarray(triangles, TRIANGLE)
+        n = tris.size
+        cap = max(1, 2 * n - 1)
+        out_t = np.zeros(n, TRIANGLE) if want_arrays else None
+        out_n = np.zeros(cap, NODE) if want_arrays else None
+        nn, ms = C.c_int32(), C.c_float()
+        self._check(self._lib.pt_build_scene(self._h, _ptr(mats), mats.size, _ptr(tris), n, _ptr(out_t), _ptr(out_n), cap, C.byref(nn), C.byref(ms)))
+        return (out_t, out_n[:nn.value].copy(), ms.value) if want_arrays else ms.value
+
     def stats(self):
         s = _native.pt_stats()
         self._check(self._lib.pt_get_stats(self._h, C.byref(s)))

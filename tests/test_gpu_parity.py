@@ -182,6 +182,47 @@ def test_gpu_bvh_build_is_byte_identical(pa, bundled, soup50k):
     wf.close()
 
 
+def test_device_built_scene_renders_identically(pa, ob, bundled, wf_bundled):
+    """pt_build_scene (build + repack on the GPU) against pt_upload_scene of the CPU-built arrays: same hits, same
+    counters, same image, and the arrays handed back are the CPU build's."""
+    mats, tris, nodes, refs = bundled.arrays(references=True)
+    wf = pa.Wavefront(nee=True, rng_mode=1, traversal_stats=True)
+    got_t, got_n, ms = wf.build_scene(mats, refs, want_arrays=True)
+    assert got_t.tobytes() == tris.tobytes() and got_n.tobytes() == nodes.tobytes()
+    rng = np.random.default_rng(11)
+    n = 20000
+    rays = np.zeros((n, 6), np.float32)
+    rays[:, 0:3] = rng.uniform(-8, 8, (n, 3)).astype(np.float32) + np.array([0, 9, 0], np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays[:, 3:6] = d / np.sqrt((d * d).sum(1, dtype=np.float32))[:, None]
+    rays[::7, 4] = 0.0                      # some rays for the two-wide pass (pair records)
+    a, b = wf.trace_closest(rays), wf_bundled.trace_closest(rays)
+    for k in ("tri", "t", "uv"):
+        assert np.array_equal(bits(a[k]), bits(b[k])), k
+    tmax = rng.uniform(1, 30, n).astype(np.float32)
+    assert np.array_equal(wf.trace_occluded(rays, tmax), wf_bundled.trace_occluded(rays, tmax))
+    w = h = 128
+    ref = pa.Wavefront(nee=True, rng_mode=1, traversal_stats=True)
+    ref.upload_scene(mats, tris, nodes)
+    fs = bundled_view(bundled, w, h)
+    imgs, stats = [], []
+    for x in (wf, ref):
+        x.allocate(w, h)
+        x.reset_stats()
+        x.invoke(fs, spp=2, max_bounces=4)
+        imgs.append(x.read_image())
+        stats.append(x.stats())
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
+    for k in ("extend_rays", "shadow_rays", "extend_steps", "extend_tris", "shadow_steps", "shadow_tris"):
+        assert stats[0][k] == stats[1][k], k
+    # an empty and a two-triangle scene through the same entry point
+    wf.build_scene(mats, refs[:0])
+    assert (wf.trace_closest(rays[:8])["tri"] == -1).all()
+    wf.build_scene(mats, refs[:2])
+    wf.close()
+    ref.close()
+
+
 def test_tiny_and_empty_scenes(pa, ob):
     # 2 triangles: the root stays a leaf (Count < 3, Accelerator.cs:138)
     s = ob.Scene(pa_assets())

@@ -34,7 +34,7 @@ def main():
     t0 = time.perf_counter()
     s.build(args.threads)
     host_s = time.perf_counter() - t0
-    _, tris, nodes = s.arrays()
+    mats, tris, nodes = s.arrays()
     print(f"scene {args.scene}: {tris.size} triangles, {nodes.size} nodes; host build on {args.threads} threads {host_s * 1e3:.0f} ms", flush=True)
     wf = pa.Wavefront()
     for it in range(3):
@@ -42,6 +42,13 @@ def main():
         gt, gn, ms = wf.build_bvh(tris)     # input order: the host build's output order (any order is a valid input)
         wall = time.perf_counter() - t0
         print(f"  GPU build: {ms:.1f} ms on the device, {wall * 1e3:.0f} ms with transfers and host copies; {gn.size} nodes, {tris.size / ms / 1e3:.1f} Mtris/s", flush=True)
+    t0 = time.perf_counter()
+    wf.upload_scene(mats, tris, nodes)
+    print(f"  pt_upload_scene of host-built arrays (CPU repack + transfers): {(time.perf_counter() - t0) * 1e3:.0f} ms", flush=True)
+    for it in range(2):
+        t0 = time.perf_counter()
+        ms = wf.build_scene(mats, tris)
+        print(f"  pt_build_scene (build + repack on the device): {ms:.1f} ms on the device, {(time.perf_counter() - t0) * 1e3:.0f} ms wall with the triangle upload", flush=True)
     if args.check:
         h = Scene("")
         h.add_triangles(tris)
