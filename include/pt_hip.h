@@ -58,7 +58,8 @@ typedef struct pt_stats {
     uint64_t paths;             /* primary rays generated */
     uint64_t extend_rays;       /* rays traced by extend (primary + bounce) */
     uint64_t shadow_rays;       /* rays traced by connect */
-    uint64_t extend_steps;      /* node-pair fetches in extend   (traversal_stats) */
+    uint64_t extend_steps;      /* node records fetched in extend: quad records, plus pair records for the rays
+                                   of the two-wide pass   (traversal_stats) */
     uint64_t extend_tris;       /* triangle tests in extend      (traversal_stats) */
     uint64_t shadow_steps;
     uint64_t shadow_tris;
@@ -81,8 +82,8 @@ const char* pt_last_error(pt_ctx* ctx);
 
 /* Replaces: Scene.CopyToDevice -> Buffer<T>.CopyToDevice for bindings 10/11/12,
  * PathTracer/Scene.cs:176-183, PathTracer/Library/Graphics/Buffer.cs:94-126.
- * Copies; validates child indices and leaf ranges (PT_E_BAD_BVH); repacks on the
- * device into 64-byte sibling-pair nodes and 48-byte hot/cold triangle records;
+ * Copies; validates child indices and leaf ranges (PT_E_BAD_BVH); repacks into 128-byte quad records (every
+ * other level of the tree), 64-byte sibling-pair records and 48-byte hot/cold triangle records;
  * builds the emissive-triangle table. */
 int pt_upload_scene(pt_ctx* ctx, const void* materials, int32_t n_materials,
                     const void* triangles, int32_t n_triangles,
