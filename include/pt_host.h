@@ -60,6 +60,12 @@ int pth_scene_generate_soup(pth_scene* s, int32_t n_triangles, uint32_t seed);
  * triangle arrays are identical for every thread count. */
 int pth_scene_build(pth_scene* s, int32_t threads);
 
+/* Cache file of a built scene (no reference counterpart: the reference rebuilds at every start): "PTSCENE1", int32
+ * counts of materials, triangles, nodes and a zero, then Material[], Triangle[] (built order) and Node[] verbatim.
+ * pth_scene_load replaces the scene's contents; pth_scene_arrays then returns the stored arrays without a build. */
+int pth_scene_save(pth_scene* s, const char* path);
+int pth_scene_load(pth_scene* s, const char* path);
+
 /* out4 = { materials, triangles, nodes, tree depth } */
 int pth_scene_counts(pth_scene* s, int32_t* out4);
 

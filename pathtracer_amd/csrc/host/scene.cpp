@@ -520,6 +520,48 @@ int pth_scene_generate_soup(pth_scene* s, int32_t n, uint32_t seed) { PTH_GUARD(
 
 int pth_scene_build(pth_scene* s, int32_t threads) { PTH_GUARD(s->accelerator.Build(threads)) }
 
+// Built-scene cache file: "PTSCENE1", three int32 counts (materials, triangles, nodes), one int32 zero, then the three
+// arrays verbatim (Material 48 B, Triangle 112 B in built order, Node 32 B): what Scene.CopyToDevice uploads.
+int pth_scene_save(pth_scene* s, const char* path) {
+    PTH_GUARD(
+        const Accelerator& a = s->accelerator;
+        if (a.nodes.empty()) throw std::runtime_error("pth_scene_save: the scene has not been built");
+        FILE* f = std::fopen(path, "wb");
+        if (!f) throw std::runtime_error(std::string("cannot write ") + path);
+        const int32_t head[4] = {(int32_t)s->materials.size(), (int32_t)a.triangles.size(), (int32_t)a.nodes.size(), 0};
+        bool ok = std::fwrite("PTSCENE1", 1, 8, f) == 8 && std::fwrite(head, 4, 4, f) == 4;
+        ok = ok && std::fwrite(s->materials.data(), sizeof(Material), s->materials.size(), f) == s->materials.size();
+        ok = ok && std::fwrite(a.triangles.data(), sizeof(Triangle), a.triangles.size(), f) == a.triangles.size();
+        ok = ok && std::fwrite(a.nodes.data(), sizeof(Node), a.nodes.size(), f) == a.nodes.size();
+        ok = (std::fclose(f) == 0) && ok;
+        if (!ok) throw std::runtime_error(std::string("short write to ") + path))
+}
+
+int pth_scene_load(pth_scene* s, const char* path) {
+    PTH_GUARD(
+        FILE* f = std::fopen(path, "rb");
+        if (!f) throw std::runtime_error(std::string("cannot read ") + path);
+        char magic[8];
+        int32_t head[4];
+        bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "PTSCENE1", 8) == 0 && std::fread(head, 4, 4, f) == 4;
+        ok = ok && head[0] >= 0 && head[1] >= 0 && head[2] >= 1 && head[2] <= 2 * std::max(head[1], 1);
+        std::vector<Material> m;
+        std::vector<Triangle> t;
+        std::vector<Node> n;
+        if (ok) {
+            m.resize(head[0]); t.resize(head[1]); n.resize(head[2]);
+            ok = std::fread(m.data(), sizeof(Material), m.size(), f) == m.size() && std::fread(t.data(), sizeof(Triangle), t.size(), f) == t.size() &&
+                 std::fread(n.data(), sizeof(Node), n.size(), f) == n.size() && std::fgetc(f) == EOF;
+        }
+        std::fclose(f);
+        if (!ok) throw std::runtime_error(std::string(path) + " is not a scene cache file");
+        s->materials.swap(m);
+        s->accelerator.Clear();
+        for (const Triangle& tri : t) s->accelerator.AddTriangle(tri);   // insertion order := built order (a rebuild keeps working)
+        s->accelerator.triangles.swap(t);
+        s->accelerator.nodes.swap(n))
+}
+
 int pth_scene_counts(pth_scene* s, int32_t* out4) {
     PTH_GUARD(out4[0] = (int32_t)s->materials.size(); out4[1] = (int32_t)s->accelerator.triangles.size();
               out4[2] = (int32_t)s->accelerator.nodes.size(); out4[3] = s->accelerator.Depth())

@@ -39,6 +39,8 @@ def _lib():
         lib.pth_scene_initialize_extended.argtypes = [vp, i32, i32]
         lib.pth_scene_generate_instances.argtypes = [vp, i32, i32]
         lib.pth_scene_build.argtypes = [vp, i32]
+        lib.pth_scene_save.argtypes = [vp, C.c_char_p]
+        lib.pth_scene_load.argtypes = [vp, C.c_char_p]
         lib.pth_scene_counts.argtypes = [vp, vp]
         lib.pth_scene_arrays.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         lib.pth_camera_basis.argtypes = [vp, vp, vp, vp, vp]
@@ -102,6 +104,14 @@ class Scene:
 
     def build(self, threads=1):
         _chk(self._lib.pth_scene_build(self._h, threads))
+
+    def save(self, path):
+        """Write the built scene (materials, triangles in built order, nodes) to a cache file."""
+        _chk(self._lib.pth_scene_save(self._h, os.fsencode(path)))
+
+    def load(self, path):
+        """Replace the scene by a cache file written by save(); no build is needed afterwards."""
+        _chk(self._lib.pth_scene_load(self._h, os.fsencode(path)))
 
     def counts(self):
         out = np.zeros(4, np.int32)

@@ -113,6 +113,28 @@ def test_host_synthetic_large_scene_generators(host):
         assert (m["emissive"][:, :3].sum(1) > 0).sum() >= 1
 
 
+def test_scene_cache_file_round_trip(host, tmp_path):
+    s = host.Scene()
+    s.initialize_scene(7)
+    with pytest.raises(host.HostError):
+        s.save(str(tmp_path / "unbuilt.bin"))
+    s.build(2)
+    path = str(tmp_path / "scene.bin")
+    s.save(path)
+    c = s.counts()
+    assert os.path.getsize(path) == 24 + 48 * c["materials"] + 112 * c["triangles"] + 32 * c["nodes"]
+    t = host.Scene("")
+    t.load(path)
+    assert same(s.arrays(), t.arrays()) and t.counts() == c
+    t.build(2)                                 # rebuilding from the stored order gives a valid tree over the same triangles
+    assert t.counts()["triangles"] == c["triangles"]
+    (tmp_path / "bad.bin").write_bytes(open(path, "rb").read()[:-5])
+    with pytest.raises(host.HostError):
+        t.load(str(tmp_path / "bad.bin"))
+    with pytest.raises(host.HostError):
+        t.load(str(tmp_path / "missing.bin"))
+
+
 def test_host_obj_text_loader(host, ob, tmp_path):
     """The OBJ/MTL text path of the host mirror (Mesh.cs:72-329) on a file written here: quads, negative
     indices, missing normals, tabs, a material library."""
