@@ -177,6 +177,32 @@ def test_gpu_bvh_build_is_byte_identical(pa, bundled, soup50k):
         assert got_n.size == want_n.size, name
         assert got_n.tobytes() == want_n.tobytes(), name
         assert got_t.tobytes() == want_t.tobytes(), name
+    # large nodes (the chunked partition) whose splits fail: 3,000 copies each of two triangles -> one split, two huge leaves
+    two = np.concatenate([np.repeat(bt[5:6], 3000), np.repeat(bt[9000:9001], 3000)])
+    two = two[rng.permutation(two.size)]
+    want_t, want_n = _host_build(pa, two)
+    got_t, got_n, _ = wf.build_bvh(two)
+    assert got_n.tobytes() == want_n.tobytes() and got_t.tobytes() == want_t.tobytes()
+    assert (want_n["count"] > 15).any(), "meant to produce leaves too large for a packed entry"
+    # ... and such leaves traverse correctly (leaf phases split a 3,000-triangle leaf over many rounds)
+    from pathtracer_amd.host import Scene
+    hs = Scene("")
+    hs.add_triangles(two)
+    hs.build(1)
+    big = pa.Wavefront()
+    big.upload_scene(bundled.arrays()[0], *hs.arrays()[1:])
+    c = (two["v1"]["position"] + two["v2"]["position"] + two["v3"]["position"]) / np.float32(3)
+    o = c[:256] + np.array([0.3, 4.0, 0.2], np.float32)
+    d = c[:256] - o
+    rays = np.concatenate([o, d / np.sqrt((d * d).sum(1, dtype=np.float32))[:, None]], axis=1).astype(np.float32)
+    g = big.trace_closest(rays)
+    assert (g["tri"] >= 0).all()
+    # every copy is hit at the same distance: the smallest index among the copies wins
+    first_of = {}
+    for i, t in enumerate(want_t):
+        first_of.setdefault(t["v1"]["position"].tobytes(), i)
+    assert set(g["tri"].tolist()) <= set(first_of.values())
+    big.close()
     t0, n0, _ = wf.build_bvh(bt[:0])
     assert t0.size == 0 and n0.size == 1 and n0["count"][0] == 0
     wf.close()
