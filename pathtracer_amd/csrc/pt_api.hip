@@ -239,7 +239,8 @@ int pt_create(const pt_config* cfg, pt_ctx** out) {
     c->fit_connect = perCu;
     perCu = std::min(perCu, 7);
     c->grid_connect = c->num_cu * perCu;
-    c->grid_shade = c->num_cu * 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_shade, PT_SHADE_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 2;
+    c->grid_shade = c->num_cu * perCu;   // one resident round: the kernel strides over the queue
     c->grid_special = c->num_cu * 2;
     *out = c;
     return PT_OK;
