@@ -5,7 +5,9 @@
 #include "pt_device.hpp"
 
 #define PT_BLOCK 256
+#ifndef PT_SHADE_BLOCK
 #define PT_SHADE_BLOCK 512
+#endif
 #ifndef PT_TRAVERSE_WAVES
 #define PT_TRAVERSE_WAVES 5   // minimum waves per SIMD the traversal kernels are compiled for (caps their VGPRs)
 #endif
@@ -294,32 +296,34 @@ __device__ __forceinline__ int pickLight(const DevScene& sc, float r) {
     return lo;
 }
 
-// Dense output slot for every thread of the block with alive == true: wave ballots, a prefix
-// over the waves' counts in LDS, and ONE atomic per block (a single counter word sustains only
-// ~90 atomics/us, so per-wave atomics would bound the whole stage).  All threads of the block
-// must call it together.
-__device__ __forceinline__ uint32_t blockAppend(bool alive, uint32_t* counter, uint32_t* s_counts, uint32_t* s_base) {
-    const unsigned long long mask = __ballot(alive);
-    const uint32_t lane = laneId(), wave = threadIdx.x / PT_WAVE, nWaves = blockDim.x / PT_WAVE;
-    if (lane == 0) s_counts[wave] = (uint32_t)__popcll(mask);
+// Dense output slots in two queues at once for the threads of the block with a / b set: wave ballots, a prefix
+// over the waves' counts in LDS, and ONE atomic per queue and block (a single counter word sustains only
+// ~90 atomics/us, so per-wave atomics would bound the whole stage).  All threads of the block must call it
+// together; `lds` holds 2 x (PT_SHADE_BLOCK / 64) counts and 2 bases, and callers alternate between two such areas
+// from one call to the next, which is what makes two barriers enough.
+__device__ __forceinline__ void blockAppend2(bool a, bool b, uint32_t* counterA, uint32_t* counterB, uint32_t* lds, uint32_t* slotA, uint32_t* slotB) {
+    constexpr uint32_t W = PT_SHADE_BLOCK / PT_WAVE;
+    const unsigned long long maskA = __ballot(a), maskB = __ballot(b);
+    const uint32_t lane = laneId(), wave = threadIdx.x / PT_WAVE;
+    if (lane == 0) { lds[wave] = (uint32_t)__popcll(maskA); lds[W + wave] = (uint32_t)__popcll(maskB); }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (lane == 0 && wave < 2u) {   // one thread per queue, in different waves: the two atomics overlap
+        uint32_t* cnt = lds + wave * W;
         uint32_t total = 0;
-        for (uint32_t w = 0; w < nWaves; w++) { const uint32_t c = s_counts[w]; s_counts[w] = total; total += c; }
-        *s_base = total ? atomicAdd(counter, total) : 0u;
+        for (uint32_t w = 0; w < W; w++) { const uint32_t c = cnt[w]; cnt[w] = total; total += c; }
+        lds[2 * W + wave] = total ? atomicAdd(wave == 0u ? counterA : counterB, total) : 0u;
     }
     __syncthreads();
-    const uint32_t slot = *s_base + s_counts[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    __syncthreads();
-    return slot;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    *slotA = lds[2 * W] + lds[wave] + (uint32_t)__popcll(maskA & below);
+    *slotB = lds[2 * W + 1] + lds[W + wave] + (uint32_t)__popcll(maskB & below);
 }
 
 // shade.glsl:349-459 plus next-event estimation.  Terminated paths add their radiance to
 // plane[birth] (one live path per birth index, so a plain read-modify-write is race free);
 // survivors are appended to the other queue by wave-level ballot/prefix compaction.
 __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(DevScene sc, RenderParams rp, Queues q, Ctl* ctl, int cur) {
-    __shared__ uint32_t s_counts[2][PT_SHADE_BLOCK / PT_WAVE];
-    __shared__ uint32_t s_base[2];
+    __shared__ uint32_t s_append[2][2 * (PT_SHADE_BLOCK / PT_WAVE) + 2];
     const uint32_t n = ctl->count[cur];
     const int nxt = cur ^ 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -461,13 +465,13 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(DevScene sc, RenderPar
             }
             if (addIt) q.plane[birth] = to4(from4(q.plane[birth]) + add);
         }
-        const uint32_t slotOut = blockAppend(survive, &ctl->count[nxt], s_counts[0], &s_base[0]);
+        uint32_t slotOut, sOut;
+        blockAppend2(survive, shadow, &ctl->count[nxt], &ctl->shadow_count, s_append[it & 1u], &slotOut, &sOut);
         if (survive) {
             q.o[nxt][slotOut] = make_float4(newO.x, newO.y, newO.z, __uint_as_float(birth));
             q.d[nxt][slotOut] = make_float4(newD.x, newD.y, newD.z, __uint_as_float(newFlags));
             q.T[nxt][slotOut] = to4(newT);
         }
-        const uint32_t sOut = blockAppend(shadow, &ctl->shadow_count, s_counts[1], &s_base[1]);
         if (shadow) {
             q.so[sOut] = make_float4(sO.x, sO.y, sO.z, sTmax);
             q.sd[sOut] = make_float4(sD.x, sD.y, sD.z, __uint_as_float(birth));
