@@ -424,6 +424,56 @@ def test_batch_size_and_accumulation_invariance(pa, bundled):
         assert np.array_equal(bits(im), bits(imgs[0]))
 
 
+def test_full_size_frame_properties(pa, ob, bundled):
+    """The headline configuration at full size (1920x1080, 16 spp, 4 bounces, NEE), through properties that need no
+    CPU render: the image is the same bits for 16 samples in one batch, in batches of 5, and as 4 + 12 over two calls;
+    it is finite, non-negative, and its ray counts are the same in all three runs."""
+    w, h = 1920, 1080
+    imgs, rays = [], []
+    for batch, calls in [(16, [16]), (5, [16]), (0, [4, 12])]:
+        wf = make_wf(pa, bundled, nee=True, rng_mode=1, samples_per_batch=batch)
+        wf.allocate(w, h)
+        fs = bundled_view(bundled, w, h, frames=1)
+        for spp in calls:
+            wf.invoke(fs, spp=spp, max_bounces=4)
+            fs["frames"] += spp
+            fs["samples"] += spp
+        imgs.append(wf.read_image())
+        st = wf.stats()
+        rays.append((st["paths"], st["extend_rays"], st["shadow_rays"]))
+        assert st["stack_overflows"] == 0
+        wf.close()
+    assert rays[0][0] == w * h * 16 and rays[0] == rays[1] == rays[2]
+    assert np.isfinite(imgs[0]).all() and (imgs[0] >= 0).all() and imgs[0][..., :3].mean() > 0.05
+    assert np.array_equal(bits(imgs[1]), bits(imgs[0])) and np.array_equal(bits(imgs[2]), bits(imgs[0]))
+
+
+def test_million_triangle_soup_against_the_oracle(pa, ob):
+    """The 1M-triangle configuration's scene at full size: GPU build == oracle build, and incoherent closest / any hits
+    == the oracle's literal and canonical walks on a sample of rays."""
+    o = ob.Scene("")
+    o.soup(1000000)
+    o.build()
+    mats, tris, nodes, refs = o.arrays(references=True)
+    wf = pa.Wavefront()
+    got_t, got_n, _ = wf.build_scene(mats, refs, want_arrays=True)
+    assert got_n.tobytes() == nodes.tobytes() and got_t.tobytes() == tris.tobytes()
+    rng = np.random.default_rng(17)
+    n = 8192
+    rays = np.zeros((n, 6), np.float32)
+    rays[:, 0:3] = rng.uniform(-50, 50, (n, 3))
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays[:, 3:6] = d / np.sqrt((d * d).sum(1, dtype=np.float32))[:, None]
+    g = wf.trace_closest(rays)
+    can, lit = o.intersect(rays, "canonical", threads=8), o.intersect(rays, "literal", threads=8)
+    assert np.array_equal(g["tri"], can["tri"]) and np.array_equal(bits(g["t"]), bits(can["t"])) and np.array_equal(bits(g["uv"]), bits(can["uv"]))
+    assert np.array_equal(g["tri"], lit["tri"]) and np.array_equal(bits(g["t"]), bits(lit["t"]))
+    assert (g["tri"] >= 0).mean() > 0.5
+    tmax = rng.uniform(1, 60, n).astype(np.float32)
+    assert np.array_equal(wf.trace_occluded(rays, tmax), o.occluded(rays, tmax, threads=8))
+    wf.close()
+
+
 def test_tile_sharding_single_process(pa, ob, bundled):
     """world=3 contexts on one GPU: assembling their accumulators gives the 1-GPU image bit for bit."""
     import torch
