@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--stats", action="store_true")
     ap.add_argument("--blocks", type=int, default=0, help="resident traversal blocks per CU (0 = as many as fit)")
     ap.add_argument("--coherent", action="store_true", help="primary camera rays instead of bounce rays")
+    ap.add_argument("--sort", type=int, default=0, help="experiment: order the rays by a Morton key of the origin with this many bits per axis (+ direction octant)")
     args = ap.parse_args()
 
     import pathtracer_amd as pa
@@ -70,6 +71,15 @@ def main():
         ok = np.nonzero(hit["tri"] >= 0)[0][:n]
         p = first[ok, :3] + first[ok, 3:] * hit["t"][ok, None]
         rays = np.concatenate([p, unit(len(ok))], 1).astype(np.float32)
+    if args.sort:
+        b = args.sort
+        q = np.clip(((rays[:, :3] - lo) / (hi - lo) * (1 << b)).astype(np.int64), 0, (1 << b) - 1)
+        key = np.zeros(rays.shape[0], np.int64)
+        for bit in range(b):
+            for a in range(3):
+                key |= ((q[:, a] >> bit) & 1) << (3 * bit + a + 3)
+        key |= (rays[:, 3] > 0).astype(np.int64) | ((rays[:, 4] > 0).astype(np.int64) << 1) | ((rays[:, 5] > 0).astype(np.int64) << 2)
+        rays = np.ascontiguousarray(rays[np.argsort(key, kind="stable")])
     print(f"{rays.shape[0]} rays", flush=True)
 
     wf.reset_stats()
