@@ -71,6 +71,7 @@ typedef struct pt_stats {
     /* extend stage, traversal_stats only: iterations a wave spent on interior steps, on leaf (triangle) steps and on
      * retiring/refilling lanes; extend_steps / (64 * sched_interior) is the lane utilisation of the interior loop */
     uint64_t sched_interior, sched_leaf, sched_refill;
+    uint64_t special_rays;      /* rays (extend + connect) that took the two-wide pass: zero/denormal/non-finite components */
 } pt_stats;
 
 /* ---- lifetime --------------------------------------------------------------

@@ -29,7 +29,8 @@ class pt_stats(C.Structure):
                 ("generate_launches", C.c_uint32),
                 ("ms_generate", C.c_float), ("ms_extend", C.c_float), ("ms_shade", C.c_float), ("ms_connect", C.c_float),
                 ("ms_render", C.c_float), ("reserved", C.c_float * 3),
-                ("sched_interior", C.c_uint64), ("sched_leaf", C.c_uint64), ("sched_refill", C.c_uint64)]
+                ("sched_interior", C.c_uint64), ("sched_leaf", C.c_uint64), ("sched_refill", C.c_uint64),
+                ("special_rays", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}

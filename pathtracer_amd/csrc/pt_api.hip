@@ -901,6 +901,7 @@ int pt_get_stats(pt_ctx* c, pt_stats* out) {
     s.sched_interior = ctl.sched_interior;
     s.sched_leaf = ctl.sched_leaf;
     s.sched_refill = ctl.sched_refill;
+    s.special_rays = ctl.special_rays;
     *out = s;
     return PT_OK;
 }

@@ -84,6 +84,7 @@ struct Ctl {
     uint32_t cursor_special;
     unsigned long long paths, extend_rays, shadow_rays, extend_steps, extend_tris, shadow_steps, shadow_tris, stack_overflows;
     unsigned long long sched_interior, sched_leaf, sched_refill;   // wave iterations by kind, extend stage, instrumented builds
+    unsigned long long special_rays;                               // rays handed to the two-wide passes
 };
 
 // ------------------------------------------------ deterministic elementary fns
@@ -316,9 +317,9 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 //   through an LDS minimum on (distance, triangle index), and owners whose leaf is finished pop.  Lanes that reach a leaf wait until PT_LEAF_BATCH lanes are waiting (or nobody is left
 //   stepping), so both code paths run with many lanes active instead of a few.
 //   Lanes are persistent: a lane whose ray has ended stores the result and takes the next ray of
-//   the wave's private range; the range is replenished 256 rays at a time from the shared cursor
-//   (first range static, no atomic), so long rays do not hold 63 finished lanes hostage and the
-//   single cursor word sees one atomic per 256 rays.
+//   the wave's private range; the range is replenished from the shared cursor (first range static,
+//   no atomic) 256 rays at a time in large launches and 64 in small ones, so long rays do not hold
+//   63 finished lanes hostage and the single cursor word is not the bottleneck.
 //   The stack keeps PT_STACK_LDS entries (entry, distance: 8 bytes) per lane in LDS
 //   (lstack[e * 64 + lane]: conflict free), deeper entries in scratch.
 #define PT_LEAF_FLAG 0x80000000u
@@ -331,6 +332,12 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 #define PT_LEAF_BATCH 12
 #endif
 #define PT_NO_RAY 0xFFFFFFFFu
+#ifndef PT_GRAB_LARGE
+#define PT_GRAB_LARGE 256u
+#endif
+#ifndef PT_GRAB_SWITCH
+#define PT_GRAB_SWITCH 1024u   // rays per wave above which a launch counts as large
+#endif
 
 // Entry of a leaf with triangles [first, first+count); `bigIndex` is its row in the side table
 // when it does not fit the packed form.  Used by the upload code (host side).
@@ -358,7 +365,11 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
     const uint32_t lane = laneId();
     const uint32_t totalWaves = gridDim.x * (blockDim.x / PT_WAVE);
     const uint32_t waveId = blockIdx.x * (blockDim.x / PT_WAVE) + threadIdx.x / PT_WAVE;
-    const uint32_t grab = (cursor != nullptr && n >= totalWaves * 256u) ? 256u : 64u;
+    // Ranges are handed out in queue order (first one static, no atomic), so the waves running at any time work on
+    // neighbouring rays and share the BVH nodes they pull through L2; equal static shares per wave were 30 % slower on
+    // primary rays for that reason.  Large launches take PT_GRAB_LARGE rays per atomic to spare the cursor word,
+    // small ones 64 so that they end balanced.
+    const uint32_t grab = (cursor != nullptr && n >= totalWaves * PT_GRAB_SWITCH) ? PT_GRAB_LARGE : 64u;
     const uint32_t dynBase = totalWaves * grab;
     uint32_t rangeLo = waveId * grab, rangeHi = rangeLo + grab;
     if (rangeLo > n) rangeLo = n;

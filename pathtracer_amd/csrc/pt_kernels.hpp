@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene
     unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
     const uint32_t n = SPECIAL ? ctl->special_extend : ctl->count[cur];
     if (SPECIAL && n == 0u) return;
+    if (SPECIAL && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->special_rays, (unsigned long long)n);
     if (!SPECIAL && blockIdx.x == 0 && threadIdx.x == 0) {
         // counters of the stages that follow this launch
         ctl->count[cur ^ 1] = 0;
@@ -180,6 +181,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScen
     unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
     const uint32_t n = SPECIAL ? ctl->special_connect : ctl->shadow_count;
     if (SPECIAL && n == 0u) return;
+    if (SPECIAL && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->special_rays, (unsigned long long)n);
     if (!SPECIAL && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->shadow_rays, (unsigned long long)n);
     uint32_t steps = 0, tris = 0, overflow = 0;
     ConnectSource src;
