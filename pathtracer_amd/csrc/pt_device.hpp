@@ -365,10 +365,9 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
     const uint32_t lane = laneId();
     const uint32_t totalWaves = gridDim.x * (blockDim.x / PT_WAVE);
     const uint32_t waveId = blockIdx.x * (blockDim.x / PT_WAVE) + threadIdx.x / PT_WAVE;
-    // Ranges are handed out in queue order (first one static, no atomic), so the waves running at any time work on
-    // neighbouring rays and share the BVH nodes they pull through L2; equal static shares per wave were 30 % slower on
-    // primary rays for that reason.  Large launches take PT_GRAB_LARGE rays per atomic to spare the cursor word,
-    // small ones 64 so that they end balanced.
+    // Ranges are handed out in queue order (first one static, no atomic): rays cost very different amounts (sky against
+    // geometry), and equal static shares per wave measured 30 % slower on primary rays.  Large launches take
+    // PT_GRAB_LARGE rays per atomic to spare the cursor word, small ones 64 so that they end balanced.
     const uint32_t grab = (cursor != nullptr && n >= totalWaves * PT_GRAB_SWITCH) ? PT_GRAB_LARGE : 64u;
     const uint32_t dynBase = totalWaves * grab;
     uint32_t rangeLo = waveId * grab, rangeHi = rangeLo + grab;
