@@ -142,7 +142,7 @@ def main():
     scene = build_scene(args.workload, threads=8)
     mats, tris, nodes = scene.arrays()
     wf = pa.Wavefront(device=local_rank, nee=bool(nee), rng_mode=1, tile_rank=rank, tile_world=world,
-                      samples_per_batch=args.batch, stage_timing=True)
+                      samples_per_batch=args.batch, stage_timing=1)
     wf.upload_scene(mats, tris, nodes)
     if args.blocks >= 0:
         wf.set_option(6, args.blocks)
@@ -172,6 +172,13 @@ def main():
     wf.synchronize()
     st = wf.stats()
     wf.set_option(3, 0)
+    # ---- one un-timed plain pass with events around every stage launch: the stage breakdown
+    wf.reset_stats()
+    step()
+    wf.synchronize()
+    stb = wf.stats()
+    stage_ms = {k: stb["ms_" + k] for k in ("generate", "extend", "shade", "connect")}
+    wf.set_option(4, 2)   # the timed steps bracket only the extend launches (every pair of events costs stream time)
     steps_per_ray = st["extend_steps"] / max(1, st["extend_rays"])
     tris_per_ray = st["extend_tris"] / max(1, st["extend_rays"])
     sh_steps_per_ray = st["shadow_steps"] / max(1, st["shadow_rays"])
@@ -228,7 +235,7 @@ def main():
                          "shadow_bvh_steps_per_ray": sh_steps_per_ray, "shadow_tri_tests_per_ray": sh_tris_per_ray,
                          "launches": ext_launches, "avg_launch_ms": avg_ms, "rays_per_launch": st["extend_rays"] / ext_launches,
                          "extend_mrays_per_s": st["extend_rays"] / max(1e-9, st["ms_extend"] * 1e-3) / 1e6},
-            "stage_ms_per_step": {k: st["ms_" + k] / args.steps for k in ("generate", "extend", "shade", "connect")},
+            "stage_ms_per_step": stage_ms,   # from one un-timed step with every stage bracketed by events
         }
         if world == 1 and not args.no_cpu_baseline and args.workload in ("bundled", "c1", "soup1m", "c3"):
             fs0 = cam.frame_state(pos, tgt, frames=1, samples=0)

@@ -50,7 +50,8 @@ typedef struct pt_config {
     int32_t tile_world;
     int32_t samples_per_batch;  /* samples traced concurrently; 0 = choose from the pixel count */
     int32_t traversal_stats;    /* 1 = count BVH steps / triangle tests (slower instrumented kernels) */
-    int32_t stage_timing;       /* 1 = bracket every stage launch with events (pt_get_stats ms_*) */
+    int32_t stage_timing;       /* 1 = bracket every stage launch with events (pt_get_stats ms_*), 2 = the extend
+                                   launches only (a pair of events costs about 5 us of stream time) */
     int32_t reserved[7];
 } pt_config;
 

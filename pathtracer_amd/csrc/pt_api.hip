@@ -125,7 +125,7 @@ hipEvent_t getEvent(pt_ctx* c) {
 struct StageTimer {
     pt_ctx* c; int stage; hipEvent_t a = nullptr, b = nullptr;
     StageTimer(pt_ctx* ctx, int s) : c(ctx), stage(s) {
-        if (c->cfg.stage_timing) { a = getEvent(c); b = getEvent(c); if (a) (void)hipEventRecord(a, c->stream); }
+        if (c->cfg.stage_timing == 1 || (c->cfg.stage_timing == 2 && s == 1)) { a = getEvent(c); b = getEvent(c); if (a) (void)hipEventRecord(a, c->stream); }
     }
     ~StageTimer() {
         if (a && b) { (void)hipEventRecord(b, c->stream); c->spans.push_back({a, b, stage}); }
@@ -268,7 +268,7 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
         case PT_OPT_NEE: c->cfg.nee = value ? 1 : 0; break;
         case PT_OPT_RNG_MODE: if (value != 0 && value != 1) FAIL(c, PT_E_INVALID_ARG, "rng_mode %d", value); c->cfg.rng_mode = value; break;
         case PT_OPT_TRAVERSAL_STATS: c->cfg.traversal_stats = value ? 1 : 0; break;
-        case PT_OPT_STAGE_TIMING: c->cfg.stage_timing = value ? 1 : 0; break;
+        case PT_OPT_STAGE_TIMING: if (value < 0 || value > 2) FAIL(c, PT_E_INVALID_ARG, "stage_timing %d", value); c->cfg.stage_timing = value; break;
         case PT_OPT_TRAVERSE_BLOCKS_PER_CU:
             if (value < 0 || value > 16) FAIL(c, PT_E_INVALID_ARG, "traverse blocks per CU %d", value);
             c->grid_extend = c->num_cu * std::min(value ? value : 7, c->fit_extend);
