@@ -220,7 +220,8 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_bin(const float4* cent, const flo
         const uint32_t id = order[i];
         const float c = axisOf(cent[id], s.axis);
         const float b = (c - s.k0) * s.k1;
-        const int j = (int)b;
+        int j = (int)b;
+        j = j < 0 ? 0 : (j > PTB_BINS - 1 ? PTB_BINS - 1 : j);   // only non-finite input can leave the range (the C# build throws there)
         bin_of[i] = (uint8_t)j;
         const float4 lo = pmin[id], hi = pmax[id];
         const uint32_t klo[3] = {fkey(lo.x), fkey(lo.y), fkey(lo.z)}, khi[3] = {fkey(hi.x), fkey(hi.y), fkey(hi.z)};

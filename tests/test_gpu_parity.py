@@ -203,6 +203,12 @@ def test_gpu_bvh_build_is_byte_identical(pa, bundled, soup50k):
         first_of.setdefault(t["v1"]["position"].tobytes(), i)
     assert set(g["tri"].tolist()) <= set(first_of.values())
     big.close()
+    # non-finite coordinates (the C# build throws IndexOutOfRange): no fault here, every triangle still lands in a leaf
+    bad = bt[:5000].copy()
+    bad["v2"]["position"][7, 1] = np.nan
+    bad["v1"]["position"][99, 0] = np.inf
+    _, bn, _ = wf.build_bvh(bad)
+    assert bn[bn["count"] > 0]["count"].sum() == bad.size
     t0, n0, _ = wf.build_bvh(bt[:0])
     assert t0.size == 0 and n0.size == 1 and n0["count"][0] == 0
     wf.close()
