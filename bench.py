@@ -234,7 +234,12 @@ def main():
                          "bytes_per_ray": b_ray, "bvh_steps_per_ray": steps_per_ray, "tri_tests_per_ray": tris_per_ray,
                          "shadow_bvh_steps_per_ray": sh_steps_per_ray, "shadow_tri_tests_per_ray": sh_tris_per_ray,
                          "launches": ext_launches, "avg_launch_ms": avg_ms, "rays_per_launch": st["extend_rays"] / ext_launches,
-                         "extend_mrays_per_s": st["extend_rays"] / max(1e-9, st["ms_extend"] * 1e-3) / 1e6},
+                         "extend_mrays_per_s": st["extend_rays"] / max(1e-9, st["ms_extend"] * 1e-3) / 1e6,
+                         # frac > 1 means the caches, not HBM, serve the algorithmic bytes.  What does bound a gather of random
+                         # records is the rate tools/micro/tcp_coalesce.hip measures (L1/L2-resident table: 196 G records/s,
+                         # Infinity-Cache-resident: 58 G records/s; profiles/r01_micro_gather.txt):
+                         "gather_records_per_s": (steps_per_ray + tris_per_ray) * st["extend_rays"] / max(1e-9, st["ms_extend"] * 1e-3),
+                         "gather_ceiling_records_per_s": {"l2_resident": 196e9, "infinity_cache_resident": 58e9}},
             "stage_ms_per_step": stage_ms,   # from one un-timed step with every stage bracketed by events
         }
         if world == 1 and not args.no_cpu_baseline and args.workload in ("bundled", "c1", "soup1m", "c3"):
