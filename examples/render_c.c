@@ -1,0 +1,80 @@
+/*
+ * A host written in plain C against the two C ABIs, the way the reference's C# host would use them through P/Invoke:
+ *   libpt_host.so (pt_host.h)  Scene recipe, BVH build, camera   — stands in for the C# classes that a .NET host keeps
+ *   libpt_hip.so  (pt_hip.h)   upload, render, read the image    — what replaces Wavefront.cs and the GL buffers
+ *
+ *   render_c <meshes.bin> <width> <height> <spp> <bounces> <out.raw> [gpu-build]
+ *
+ * Game.Initialize order (Game.cs:29-55): camera set at (0,2,15) -> (0,3,0) before the scene exists (focal distance 20),
+ * InitializeScene(11), CopyToDevice, then frames with Frames = Samples = k.  Writes width*height float4 and prints an
+ * FNV-1a checksum of the bytes.  With a 7th argument the tree is built on the GPU (pt_build_scene) from the host-built
+ * triangle order, which is a valid insertion order of its own.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "pt_hip.h"
+#include "pt_host.h"
+
+#define HOST(call) do { if ((call) != 0) { fprintf(stderr, "%s: %s\n", #call, pth_last_error()); return 1; } } while (0)
+#define GPU(call) do { if ((call) != PT_OK) { fprintf(stderr, "%s: %s\n", #call, pt_last_error(ctx)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 7) { fprintf(stderr, "usage: %s meshes.bin width height spp bounces out.raw [gpu-build]\n", argv[0]); return 2; }
+    const int width = atoi(argv[2]), height = atoi(argv[3]), spp = atoi(argv[4]), bounces = atoi(argv[5]);
+
+    pth_scene* scene = pth_scene_create(argv[1]);
+    if (!scene) { fprintf(stderr, "pth_scene_create: %s\n", pth_last_error()); return 1; }
+    HOST(pth_scene_initialize(scene, 11));
+    HOST(pth_scene_build(scene, 4));
+    int32_t counts[4];
+    const void *materials, *triangles, *nodes;
+    HOST(pth_scene_counts(scene, counts));
+    HOST(pth_scene_arrays(scene, &materials, &triangles, &nodes));
+
+    pt_ctx* ctx = NULL;
+    pt_config cfg;
+    pt_default_config(&cfg);
+    cfg.nee = 1;
+    cfg.rng_mode = 1;
+    GPU(pt_create(&cfg, &ctx));
+    if (argc > 7) {
+        int32_t n_nodes = 0;
+        GPU(pt_build_scene(ctx, materials, counts[0], triangles, counts[1], NULL, NULL, 0, &n_nodes, NULL));
+    } else {
+        GPU(pt_upload_scene(ctx, materials, counts[0], triangles, counts[1], nodes, counts[2]));
+    }
+    GPU(pt_resize(ctx, width, height));
+    struct { int32_t width, height, pad[2]; float sky[4]; } rs = {width, height, {0, 0}, {142.0f / 255.0f, 178.0f / 255.0f, 237.0f / 255.0f, 1.0f}};   /* State.cs:20-27, Game.cs:13 */
+    GPU(pt_set_render_state(ctx, &rs));
+
+    /* Camera.Set before the scene exists: the autofocus ray misses, focal distance = the cap (Camera.cs:89-95) */
+    const float pos[3] = {0, 2, 15}, target[3] = {0, 3, 0};
+    float forward[3], right[3], up[3], focal = 0;
+    struct { int32_t frames, samples; float focal; int32_t pad; uint8_t camera[96]; } fs;   /* State.cs:29-41 */
+    memset(&fs, 0, sizeof fs);
+    HOST(pth_camera_basis(pos, target, forward, right, up));
+    HOST(pth_camera_state(pos, forward, right, up, 1.0f / 0.0f, width, height, fs.camera, &focal));
+    fs.frames = 1;
+    fs.samples = 0;
+    fs.focal = focal;
+    GPU(pt_render(ctx, &fs, spp, bounces));
+
+    float* image = (float*)malloc((size_t)width * height * 16);
+    GPU(pt_read_image(ctx, image));
+    uint64_t h = 1469598103934665603ull;
+    const unsigned char* bytes = (const unsigned char*)image;
+    for (size_t i = 0; i < (size_t)width * height * 16; i++) { h ^= bytes[i]; h *= 1099511628211ull; }
+    FILE* f = fopen(argv[6], "wb");
+    if (!f || fwrite(image, 16, (size_t)width * height, f) != (size_t)width * height) { fprintf(stderr, "cannot write %s\n", argv[6]); return 1; }
+    fclose(f);
+    pt_stats st;
+    GPU(pt_get_stats(ctx, &st));
+    printf("%dx%d %d spp: %llu extend rays, %llu shadow rays, checksum %016llx\n", width, height, spp, (unsigned long long)st.extend_rays,
+           (unsigned long long)st.shadow_rays, (unsigned long long)h);
+    free(image);
+    pt_destroy(ctx);
+    pth_scene_destroy(scene);
+    return 0;
+}

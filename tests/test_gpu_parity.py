@@ -5,6 +5,8 @@ compared bit for bit.  Radiance is compared with relative RMSE <= 1e-6 AND (stro
 of differing pixels is reported and required to be zero where every operation is an IEEE
 +,-,*,/,sqrt (which is the whole pipeline: the transcendentals are fixed polynomials on both sides).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -478,6 +480,33 @@ def test_million_triangle_soup_against_the_oracle(pa, ob):
     tmax = rng.uniform(1, 60, n).astype(np.float32)
     assert np.array_equal(wf.trace_occluded(rays, tmax), o.occluded(rays, tmax, threads=8))
     wf.close()
+
+
+def test_plain_c_host_renders_the_same_image(pa, bundled, tmp_path):
+    """examples/render_c (plain C over pt_host.h + pt_hip.h, no Python in the process) against the ctypes path: same
+    bytes, with the CPU-built upload and with the GPU build + repack."""
+    import subprocess
+    from conftest import MESHES, ROOT
+    w, h, spp, bounces = 160, 96, 3, 4
+    wf = make_wf(pa, bundled, nee=True, rng_mode=1)
+    wf.allocate(w, h)
+    fs = bundled_view(bundled, w, h, frames=1)
+    fs["samples"] = 0
+    wf.invoke(fs, spp=spp, max_bounces=bounces)
+    want = wf.read_image()
+    wf.close()
+    for extra in ([], ["gpu-build"]):
+        out = tmp_path / "img.raw"
+        r = subprocess.run([os.path.join(ROOT, "examples", "render_c"), MESHES, str(w), str(h), str(spp), str(bounces), str(out)] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = np.fromfile(out, np.float32).reshape(h, w, 4)
+        if not extra:
+            assert np.array_equal(bits(got), bits(want)), r.stdout
+        else:
+            # a different insertion order gives a different (valid) tree and light-table order: another estimate of
+            # the same picture
+            assert np.isfinite(got).all() and abs(float(got[..., :3].mean()) / float(want[..., :3].mean()) - 1.0) < 0.03, r.stdout
 
 
 def test_tile_sharding_single_process(pa, ob, bundled):

@@ -175,6 +175,16 @@ def test_c_abi_exports_every_declared_symbol():
     assert set(_native.PT_HIP_SYMBOLS) == set(re.findall(r"\b(pt_[a-z_0-9]+)\s*\(", re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pt_hip.h")).read(), flags=re.S)))
 
 
+def test_headers_are_plain_c(tmp_path):
+    """include/*.h compile as C99 with -pedantic, and the C example builds against both libraries."""
+    src = tmp_path / "h.c"
+    src.write_text('#include "pt_hip.h"\n#include "pt_host.h"\nint main(void) { pt_config c; return pt_default_config(&c) == PT_OK ? (int)sizeof(pt_stats) * 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(os.path.join(ROOT, "examples", "render_c")), "run __graft_entry__.build() first"
+
+
 def test_missing_library_is_an_error(monkeypatch):
     from pathtracer_amd import _native
     monkeypatch.setattr(_native, "_hip", None)
