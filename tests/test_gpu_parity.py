@@ -613,3 +613,57 @@ def test_two_processes_share_one_gpu(tmp_path):
                         "--master-port", "29617", str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "RANKS_OK" in r.stdout
+
+
+NCCL_WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+import pathtracer_amd as pa
+from pathtracer_amd import tiles
+from pathtracer_amd.host import Scene, Camera
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+w, h, spp = 200, 120, 3
+s = Scene(); s.initialize_scene(11); s.build(2)
+fs = Camera(w, h).frame_state((0, 2, 15), (0, 3, 0), frames=1, samples=0)
+wf = pa.Wavefront(device=0, nee=True, rng_mode=1, tile_rank=0, tile_world=1)
+wf.upload_scene(*s.arrays())
+wf.allocate(w, h)
+gather = tiles.AccumulatorGather(wf, dst=0)
+assert gather.on_device
+for k in range(2):                      # two images: the second gather is ordered after the first by stream semantics
+    wf.invoke(fs, spp=spp, max_bounces=4, wait=False)
+    fs["frames"] += spp
+    fs["samples"] += spp
+    res = gather()
+torch.cuda.synchronize()
+assert res.is_cuda and tuple(res.shape[:1]) == (1,)
+img = wf.assemble_tiles(res.data_ptr(), 1, 2 * spp)
+want = wf.read_image()
+assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
+t = torch.ones(4, device="cuda")
+dist.all_reduce(t)
+dist.barrier()
+wf.close()
+dist.destroy_process_group()
+print("NCCL_OK")
+"""
+
+
+def test_rccl_single_rank_gather(tmp_path):
+    """The RCCL ("nccl") code path of the tile gather on the one GPU there is: process group, device-resident snapshot,
+    gather on RCCL's stream, assembly from the gathered tensor.  (More ranks need more GPUs; the partition logic is
+    covered by the gloo tests.)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "NCCL_OK" in r.stdout
