@@ -357,6 +357,53 @@ def test_bad_bvh_rejected(pa, ob, bundled):
     wf.close()
 
 
+def test_context_lifecycle(pa, bundled, cornell):
+    """One context through the sequence a host goes through — wrong-order calls are refused, resizing and replacing
+    the scene leave no stale state: every image equals a fresh context's."""
+    def fresh(scene, w, h, spp, frames):
+        x = make_wf(pa, scene, nee=True, rng_mode=1)
+        x.allocate(w, h)
+        f = bundled_view(scene, w, h, frames=frames)
+        x.invoke(f, spp=spp, max_bounces=4)
+        img = x.read_image()
+        x.close()
+        return img
+
+    wf = pa.Wavefront(nee=True, rng_mode=1)
+    fs = bundled_view(bundled, 64, 48, frames=1)
+    with pytest.raises(pa.PtError) as e:
+        wf.invoke(fs, spp=1, max_bounces=4)                    # no scene
+    assert e.value.code == -6
+    wf.upload_scene(*bundled.arrays())
+    with pytest.raises(pa.PtError) as e:
+        wf.invoke(fs, spp=1, max_bounces=4)                    # no image size
+    assert e.value.code == -6
+    with pytest.raises(pa.PtError):
+        wf.allocate(0, 48)
+    wf.allocate(64, 48)
+    with pytest.raises(pa.PtError):
+        wf.invoke(fs, spp=0, max_bounces=4)
+    wf.invoke(fs, spp=2, max_bounces=4)
+    assert np.array_equal(bits(wf.read_image()), bits(fresh(bundled, 64, 48, 2, 1)))
+    wf.allocate(200, 104)                                       # larger: queues are reallocated, accumulation restarts
+    fs = bundled_view(bundled, 200, 104, frames=3)
+    wf.invoke(fs, spp=3, max_bounces=4)
+    assert np.array_equal(bits(wf.read_image()), bits(fresh(bundled, 200, 104, 3, 3)))
+    wf.upload_scene(*cornell.arrays())                          # another scene into the same context
+    wf.reset_accumulation()
+    fs = bundled_view(cornell, 200, 104, frames=1)
+    wf.invoke(fs, spp=2, max_bounces=4)
+    assert np.array_equal(bits(wf.read_image()), bits(fresh(cornell, 200, 104, 2, 1)))
+    mats, tris, nodes, refs = bundled.arrays(references=True)   # ... and a scene built on the GPU into it
+    wf.build_scene(mats, refs)
+    wf.allocate(64, 48)
+    fs = bundled_view(bundled, 64, 48, frames=1)
+    wf.invoke(fs, spp=2, max_bounces=4)
+    assert np.array_equal(bits(wf.read_image()), bits(fresh(bundled, 64, 48, 2, 1)))
+    assert wf.stats()["stack_overflows"] == 0
+    wf.close()
+
+
 @pytest.mark.parametrize("nee,rng_mode,bounces", [(0, 0, 10), (1, 0, 4), (1, 1, 4), (0, 1, 2)])
 def test_radiance_bundled_256(pa, ob, bundled, wf_bundled, nee, rng_mode, bounces):
     """Bundled scene, every material type (diffuse/mirror/dielectric/metal), vs the oracle path tracer."""
