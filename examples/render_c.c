@@ -3,11 +3,11 @@
  *   libpt_host.so (pt_host.h)  Scene recipe, BVH build, camera   — stands in for the C# classes that a .NET host keeps
  *   libpt_hip.so  (pt_hip.h)   upload, render, read the image    — what replaces Wavefront.cs and the GL buffers
  *
- *   render_c <meshes.bin> <width> <height> <spp> <bounces> <out.raw> [gpu-build]
+ *   render_c <meshes.bin> <width> <height> <spp> <bounces> <out.raw|out.png|out.pfm> [gpu-build]
  *
  * Game.Initialize order (Game.cs:29-55): camera set at (0,2,15) -> (0,3,0) before the scene exists (focal distance 20),
- * InitializeScene(11), CopyToDevice, then frames with Frames = Samples = k.  Writes width*height float4 and prints an
- * FNV-1a checksum of the bytes.  With a 7th argument the tree is built on the GPU (pt_build_scene) from the host-built
+ * InitializeScene(11), CopyToDevice, then frames with Frames = Samples = k.  Writes width*height float4 (or, for an output
+ * name ending in .png / .pfm, an sRGB PNG / a float PFM) and prints an FNV-1a checksum of the float4 bytes.  With a 7th argument the tree is built on the GPU (pt_build_scene) from the host-built
  * triangle order, which is a valid insertion order of its own.
  */
 #include <stdint.h>
@@ -66,9 +66,14 @@ int main(int argc, char** argv) {
     uint64_t h = 1469598103934665603ull;
     const unsigned char* bytes = (const unsigned char*)image;
     for (size_t i = 0; i < (size_t)width * height * 16; i++) { h ^= bytes[i]; h *= 1099511628211ull; }
-    FILE* f = fopen(argv[6], "wb");
-    if (!f || fwrite(image, 16, (size_t)width * height, f) != (size_t)width * height) { fprintf(stderr, "cannot write %s\n", argv[6]); return 1; }
-    fclose(f);
+    const char* ext = strrchr(argv[6], '.');
+    if (ext && strcmp(ext, ".png") == 0) HOST(pth_image_write(argv[6], image, width, height, PTH_IMAGE_PNG, PTH_TRANSFER_SRGB, 1.0f));
+    else if (ext && strcmp(ext, ".pfm") == 0) HOST(pth_image_write(argv[6], image, width, height, PTH_IMAGE_PFM, PTH_TRANSFER_DISPLAY, 1.0f));
+    else {
+        FILE* f = fopen(argv[6], "wb");
+        if (!f || fwrite(image, 16, (size_t)width * height, f) != (size_t)width * height) { fprintf(stderr, "cannot write %s\n", argv[6]); return 1; }
+        fclose(f);
+    }
     pt_stats st;
     GPU(pt_get_stats(ctx, &st));
     printf("%dx%d %d spp: %llu extend rays, %llu shadow rays, checksum %016llx\n", width, height, spp, (unsigned long long)st.extend_rays,

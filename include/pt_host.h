@@ -80,6 +80,15 @@ int pth_camera_basis(const float* position3, const float* target3, float* forwar
 int pth_camera_state(const float* position3, const float* forward3, const float* right3, const float* up3,
                      float hit_distance, int32_t width, int32_t height, void* camera_state96, float* focal);
 
+/* An image file from the rgba32f read-out of pt_read_image (row 0 = bottom row, as the reference's display reads it,
+ * PathTracer/Shaders/Quad/fragment.glsl:9-10; the reference itself never writes a file).
+ * format:   PTH_IMAGE_PFM  RGB float32, lossless;  PTH_IMAGE_PPM  binary P6;  PTH_IMAGE_PNG  8-bit RGB.
+ * transfer (8-bit formats): PTH_TRANSFER_DISPLAY  what the reference's window shows: clamp to [0,1], round(255 v);
+ *                           PTH_TRANSFER_SRGB     v * exposure, clamp, sRGB encoding. */
+enum { PTH_IMAGE_PFM = 0, PTH_IMAGE_PPM = 1, PTH_IMAGE_PNG = 2 };
+enum { PTH_TRANSFER_DISPLAY = 0, PTH_TRANSFER_SRGB = 1 };
+int pth_image_write(const char* path, const float* rgba, int32_t width, int32_t height, int32_t format, int32_t transfer, float exposure);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
 // Knuth subtractive System.Random); compile with -ffp-contract=off.
 #include "pt_host.h"
 #include "accelerator.hpp"
+#include <algorithm>
 #include <cmath>
 #include <climits>
 #include <cstdio>
@@ -470,6 +471,128 @@ struct pth_scene {
     }
 };
 
+// ---- image files -----------------------------------------------------------------------------------------------------
+// What the reference shows is the rgba32f image blitted into an 8-bit window framebuffer (Shaders/Quad/fragment.glsl:9-10):
+// row 0 of the image is the bottom row (gl_FragCoord), the value is clamped to [0,1] and stored as round(255 v).
+inline unsigned char toByte(float v) {
+    if (!(v > 0.0f)) return 0;                       // negatives and NaN
+    if (v >= 1.0f) return 255;
+    return (unsigned char)(v * 255.0f + 0.5f);
+}
+
+inline float srgbEncode(float v) {
+    if (!(v > 0.0f)) return 0.0f;
+    if (v >= 1.0f) return 1.0f;
+    return v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.0f / 2.4f) - 0.055f;
+}
+
+// 8-bit RGB rows, top row first
+std::vector<unsigned char> quantize(const float* rgba, int w, int h, int transfer, float exposure) {
+    std::vector<unsigned char> out((size_t)w * h * 3);
+    for (int y = 0; y < h; y++) {
+        const float* row = rgba + (size_t)(h - 1 - y) * w * 4;
+        unsigned char* o = out.data() + (size_t)y * w * 3;
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < 3; c++) {
+                const float v = row[4 * x + c];
+                o[3 * x + c] = toByte(transfer == 0 ? v : srgbEncode(v * exposure));
+            }
+    }
+    return out;
+}
+
+struct Crc32 {
+    uint32_t table[256];
+    Crc32() {
+        for (uint32_t n = 0; n < 256; n++) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[n] = c;
+        }
+    }
+    uint32_t run(uint32_t crc, const unsigned char* p, size_t n) const {
+        for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+        return crc;
+    }
+};
+
+void putBE32(std::vector<unsigned char>& v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((unsigned char)(x >> s)); }
+
+void pngChunk(std::vector<unsigned char>& file, const char* type, const std::vector<unsigned char>& body) {
+    static const Crc32 crc;
+    putBE32(file, (uint32_t)body.size());
+    const size_t at = file.size();
+    file.insert(file.end(), type, type + 4);
+    file.insert(file.end(), body.begin(), body.end());
+    putBE32(file, crc.run(0xFFFFFFFFu, file.data() + at, file.size() - at) ^ 0xFFFFFFFFu);
+}
+
+// PNG, 8-bit RGB, filter 0 on every row, zlib stream of stored (uncompressed) deflate blocks
+std::vector<unsigned char> encodePng(const std::vector<unsigned char>& rgb, int w, int h) {
+    std::vector<unsigned char> raw;
+    raw.reserve((size_t)h * (3 * w + 1));
+    for (int y = 0; y < h; y++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb.begin() + (size_t)y * w * 3, rgb.begin() + (size_t)(y + 1) * w * 3);
+    }
+    std::vector<unsigned char> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    size_t at = 0;
+    do {
+        const size_t n = std::min<size_t>(65535, raw.size() - at);
+        z.push_back(at + n == raw.size() ? 1 : 0);
+        z.push_back((unsigned char)(n & 0xFF)); z.push_back((unsigned char)(n >> 8));
+        z.push_back((unsigned char)(~n & 0xFF)); z.push_back((unsigned char)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + at, raw.begin() + at + n);
+        at += n;
+    } while (at < raw.size());
+    uint32_t a = 1, b = 0;                                                  // Adler-32 of the raw bytes
+    for (size_t i = 0; i < raw.size();) {
+        const size_t stop = std::min(raw.size(), i + 5552);
+        for (; i < stop; i++) { a += raw[i]; b += a; }
+        a %= 65521; b %= 65521;
+    }
+    putBE32(z, (b << 16) | a);
+    std::vector<unsigned char> file = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+    std::vector<unsigned char> ihdr;
+    putBE32(ihdr, (uint32_t)w); putBE32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    pngChunk(file, "IHDR", ihdr);
+    pngChunk(file, "IDAT", z);
+    pngChunk(file, "IEND", {});
+    return file;
+}
+
+void writeImage(const char* path, const float* rgba, int w, int h, int format, int transfer, float exposure) {
+    if (!path || !rgba || w < 1 || h < 1) throw std::runtime_error("pth_image_write: bad argument");
+    if (format < 0 || format > 2 || transfer < 0 || transfer > 1) throw std::runtime_error("pth_image_write: unknown format or transfer");
+    std::vector<unsigned char> bytes;
+    if (format == 0) {                                                      // PFM: RGB float, little endian, bottom row first
+        char head[64];
+        const int n = std::snprintf(head, sizeof head, "PF\n%d %d\n-1.0\n", w, h);
+        bytes.assign(head, head + n);
+        bytes.resize(n + (size_t)w * h * 12);
+        unsigned char* o = bytes.data() + n;
+        for (size_t i = 0; i < (size_t)w * h; i++) std::memcpy(o + 12 * i, rgba + 4 * i, 12);
+    } else {
+        const std::vector<unsigned char> rgb = quantize(rgba, w, h, transfer, exposure);
+        if (format == 1) {                                                  // PPM P6
+            char head[64];
+            const int n = std::snprintf(head, sizeof head, "P6\n%d %d\n255\n", w, h);
+            bytes.assign(head, head + n);
+            bytes.insert(bytes.end(), rgb.begin(), rgb.end());
+        } else {
+            bytes = encodePng(rgb, w, h);
+        }
+    }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) throw std::runtime_error(std::string("cannot write ") + path);
+    bool ok = std::fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) throw std::runtime_error(std::string("short write to ") + path);
+}
+
 #define PTH_GUARD(...) try { __VA_ARGS__; return 0; } catch (const std::exception& e) { g_error = e.what(); return -1; }
 
 extern "C" {
@@ -600,6 +723,10 @@ int pth_camera_state(const float* position3, const float* forward3, const float*
         const Vec3 cols[6] = {p1, p2, p3, pos, r, u};
         for (int k = 0; k < 6; k++) { o[4 * k] = cols[k].x; o[4 * k + 1] = cols[k].y; o[4 * k + 2] = cols[k].z; }
         if (focal_out) *focal_out = focal)
+}
+
+int pth_image_write(const char* path, const float* rgba, int32_t width, int32_t height, int32_t format, int32_t transfer, float exposure) {
+    PTH_GUARD(writeImage(path, rgba, width, height, format, transfer, exposure))
 }
 
 }  // extern "C"

@@ -45,6 +45,7 @@ def _lib():
         lib.pth_scene_arrays.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         lib.pth_camera_basis.argtypes = [vp, vp, vp, vp, vp]
         lib.pth_camera_state.argtypes = [vp, vp, vp, vp, C.c_float, i32, i32, vp, C.POINTER(C.c_float)]
+        lib.pth_image_write.argtypes = [C.c_char_p, vp, i32, i32, i32, i32, C.c_float]
         lib._pth_typed = True
     return lib
 
@@ -56,6 +57,23 @@ def _chk(rc):
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+IMAGE_FORMATS = {"pfm": 0, "ppm": 1, "png": 2}
+TRANSFERS = {"display": 0, "srgb": 1}
+
+
+def write_image(path, rgba, transfer="display", exposure=1.0, format=None):
+    """Write the (H, W, 4) float32 read-out of Wavefront.read_image (row 0 = bottom) as .pfm (lossless), .ppm or .png.
+    transfer="display" is what the reference's window shows (Shaders/Quad/fragment.glsl:9-10: clamp, 8 bits, no gamma);
+    "srgb" applies exposure and the sRGB curve."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    if rgba.ndim != 3 or rgba.shape[2] != 4:
+        raise ValueError("rgba must have shape (height, width, 4)")
+    fmt = format or os.path.splitext(str(path))[1].lstrip(".").lower()
+    if fmt not in IMAGE_FORMATS or transfer not in TRANSFERS:
+        raise ValueError("unknown image format %r or transfer %r" % (fmt, transfer))
+    _chk(_lib().pth_image_write(os.fsencode(path), _p(rgba), rgba.shape[1], rgba.shape[0], IMAGE_FORMATS[fmt], TRANSFERS[transfer], float(exposure)))
 
 
 class Scene:

@@ -135,6 +135,75 @@ def test_scene_cache_file_round_trip(host, tmp_path):
         t.load(str(tmp_path / "missing.bin"))
 
 
+def test_image_writers(host, tmp_path):
+    """PFM is lossless; PPM and PNG hold what the reference's window would show (clamp, 8 bits, row 0 at the bottom,
+    Shaders/Quad/fragment.glsl:9-10) or the sRGB-encoded exposure; the PNG is a valid file (CRC, zlib, Adler)."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(5)
+    w, h = 37, 300
+    img = rng.uniform(-0.2, 1.4, (h, w, 4)).astype(np.float32)
+    img[0, 0] = (np.nan, np.inf, -np.inf, 1)
+    img[1, 1] = (0.5, 1.0, 0.0, 1)
+
+    def expected(transfer, exposure):
+        v = img[::-1, :, :3].astype(np.float32)
+        if transfer == "srgb":
+            v = v * np.float32(exposure)
+            with np.errstate(invalid="ignore"):
+                c = np.clip(np.nan_to_num(v, nan=0.0, posinf=1.0, neginf=0.0), 0, 1)
+            v = np.where(c <= 0.0031308, 12.92 * c, 1.055 * np.power(c, 1 / 2.4) - 0.055)
+        with np.errstate(invalid="ignore"):
+            v = np.clip(np.nan_to_num(v, nan=0.0, posinf=1.0, neginf=0.0), 0, 1)
+        return v
+
+    def read_png(path):
+        b = open(path, "rb").read()
+        assert b[:8] == b"\x89PNG\r\n\x1a\n"
+        at, chunks = 8, []
+        while at < len(b):
+            n, = struct.unpack(">I", b[at:at + 4])
+            kind, body = b[at + 4:at + 8], b[at + 8:at + 8 + n]
+            assert struct.unpack(">I", b[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + body)
+            chunks.append((kind, body))
+            at += 12 + n
+        assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+        pw, ph, depth, colour, *_ = struct.unpack(">IIBBBBB", chunks[0][1])
+        assert (depth, colour) == (8, 2)
+        raw = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(ph, 1 + 3 * pw)
+        assert not raw[:, 0].any()
+        return raw[:, 1:].reshape(ph, pw, 3)
+
+    pfm = tmp_path / "a.pfm"
+    host.write_image(pfm, img)
+    b = open(pfm, "rb").read()
+    head = b"PF\n%d %d\n-1.0\n" % (w, h)
+    assert b.startswith(head)
+    assert np.array_equal(np.frombuffer(b[len(head):], np.float32).view(np.uint32).reshape(h, w, 3), img[:, :, :3].view(np.uint32))
+
+    for transfer, exposure in (("display", 1.0), ("srgb", 0.75)):
+        png, ppm = tmp_path / "a.png", tmp_path / "a.ppm"
+        host.write_image(png, img, transfer=transfer, exposure=exposure)
+        host.write_image(ppm, img, transfer=transfer, exposure=exposure)
+        got = read_png(png)
+        assert got.shape == (h, w, 3)
+        want = expected(transfer, exposure)
+        tol = 0 if transfer == "display" else 1        # powf rounding may move a value across a .5 boundary
+        assert np.abs(got.astype(np.int32) - np.floor(want * 255 + 0.5).astype(np.int32)).max() <= tol
+        assert tuple(got[h - 1, 0]) == (0, 255, 0) and (transfer != "display" or tuple(got[h - 2, 1]) == (128, 255, 0))
+        pb = open(ppm, "rb").read()
+        phead = b"P6\n%d %d\n255\n" % (w, h)
+        assert pb.startswith(phead) and pb[len(phead):] == got.tobytes()
+
+    big = np.full((200, 150, 4), 0.25, np.float32)     # 200 * 451 = 90,200 raw bytes: two stored deflate blocks
+    host.write_image(tmp_path / "b.png", big)
+    assert (read_png(tmp_path / "b.png") == 64).all()
+    with pytest.raises(host.HostError):
+        host.write_image(tmp_path / "no_such_dir" / "c.png", big)
+    with pytest.raises(ValueError):
+        host.write_image(tmp_path / "c.tiff", big)
+
+
 def test_host_obj_text_loader(host, ob, tmp_path):
     """The OBJ/MTL text path of the host mirror (Mesh.cs:72-329) on a file written here: quads, negative
     indices, missing normals, tabs, a material library."""
