@@ -44,7 +44,8 @@ typedef enum pt_status {
 typedef struct pt_config {
     int32_t struct_size;        /* sizeof(pt_config), for versioning */
     int32_t device;             /* HIP device ordinal */
-    int32_t nee;                /* 1 = next-event estimation at diffuse vertices (not in the reference) */
+    int32_t nee;                /* next-event estimation at diffuse vertices (not in the reference): 0 off, 1 on,
+                                   2 on with multiple importance sampling (balance heuristic with the BRDF sample) */
     int32_t rng_mode;           /* 0 = reference seeding (generate.glsl:174, shade.glsl:352), 1 = decorrelated hash */
     int32_t tile_rank;          /* this context renders pixel groups g with g % tile_world == tile_rank */
     int32_t tile_world;

@@ -197,7 +197,7 @@ struct Camera {
 // --------------------------------------------------------------- wavefront
 struct PathConfig {
     int max_bounces = 10;
-    int nee = 0;           // next-event estimation at diffuse vertices
+    int nee = 0;           // next-event estimation at diffuse vertices: 0 off, 1 on, 2 on with multiple importance sampling
     int rng_mode = 0;      // 0 = reference seeding, 1 = decorrelated hash
     int tile_rank = 0, tile_world = 1;
 };

@@ -305,6 +305,7 @@ void RenderSamples(const Scene& scene, const LightTable& lights, const RenderSta
             Vec4 T{1, 1, 1, 1};
             Vec4 plane{0, 0, 0, 0};
             bool lastSpecular = true;
+            float lastPdf = 0.0f;   // density of the direction that led to the current vertex (nee == 2 only)
             for (int bounce = 0; bounce < cfg.max_bounces; bounce++) {
                 // ---- extend (extend.glsl:301-309)
                 Ray ray = MakeRay(o, d);
@@ -326,6 +327,17 @@ void RenderSamples(const Scene& scene, const LightTable& lights, const RenderSta
                 const Material& mat = scene.materials[tri.Material];
                 if (mat.Emissive[0] > 0 || mat.Emissive[1] > 0 || mat.Emissive[2] > 0) {
                     if (!cfg.nee || lastSpecular) plane = plane + T * ld4(mat.Emissive);
+                    else if (cfg.nee == 2) {
+                        // multiple importance sampling, balance heuristic: this emitter was reached by BRDF sampling at a
+                        // vertex that also sampled the lights; pl = density of the light sampling for this point
+                        const Vec3 ng = Cross(tri.V2.Position - tri.V1.Position, tri.V3.Position - tri.V1.Position);
+                        const float cosy = fabsf(Dot(d, ng)) / sqrtf(Dot(ng, ng));
+                        const float dist2 = hit.Distance * hit.Distance;
+                        if (cosy > 0.0f && dist2 > 0.0f) {
+                            const float pl = dist2 / (cosy * lights.totalArea);
+                            plane = plane + (T * ld4(mat.Emissive)) * (lastPdf / (lastPdf + pl));
+                        }
+                    }
                     break;
                 }
                 // interpolated shading normal (extend.glsl:199-209), barycentrics of the C# test:
@@ -394,6 +406,10 @@ void RenderSamples(const Scene& scene, const LightTable& lights, const RenderSta
                             const float geom = cosx * cosy * lights.totalArea / dist2;
                             const Material& lm = scene.materials[lt.Material];
                             Vec4 c = (T * brdf) * ld4(lm.Emissive) * geom;
+                            if (cfg.nee == 2) {
+                                const float pl = dist2 / (cosy * lights.totalArea);
+                                c = c * (pl / (pl + clamp01(cosx) * INVPI));
+                            }
                             const Vec3 so = hitP + wn * EPSILON;
                             if (stats) stats->shadow_rays++;
                             if (!acc.Occluded(MakeRay(so, wn), dl * 0.999f, stats ? &stats->shadow : nullptr)) plane = plane + c;
@@ -416,6 +432,13 @@ void RenderSamples(const Scene& scene, const LightTable& lights, const RenderSta
                 d = bounceDir;
                 T = throughput;
                 lastSpecular = (mat.Type != Diffuse);
+                if (mat.Type == Diffuse && cfg.nee == 2) {   // the queue keeps the density with its low bit cleared (the bit is the specular flag)
+                    const float pdf = clamp01(Dot(normal, bounceDir)) * INVPI;
+                    uint32_t b;
+                    std::memcpy(&b, &pdf, 4);
+                    b &= ~1u;
+                    std::memcpy(&lastPdf, &b, 4);
+                }
             }
             float* px = sum + 4 * (size_t)pixel;
             px[0] += plane.x; px[1] += plane.y; px[2] += plane.z; px[3] += plane.w;

@@ -211,6 +211,7 @@ int pt_create(const pt_config* cfg, pt_ctx** out) {
     if (!cfg || !out) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: null argument");
     if (cfg->struct_size != (int32_t)sizeof(pt_config)) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: struct_size %d, expected %zu", cfg->struct_size, sizeof(pt_config));
     if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: tile rank %d of %d", cfg->tile_rank, cfg->tile_world);
+    if (cfg->nee < 0 || cfg->nee > 2) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: nee %d", cfg->nee);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) FAIL((pt_ctx*)nullptr, PT_E_NO_DEVICE, "pt_create: no HIP device");
     if (cfg->device < 0 || cfg->device >= ndev) FAIL((pt_ctx*)nullptr, PT_E_NO_DEVICE, "pt_create: device %d of %d", cfg->device, ndev);
@@ -265,7 +266,7 @@ int pt_destroy(pt_ctx* c) {
 int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
     if (!c) return PT_E_INVALID_ARG;
     switch (key) {
-        case PT_OPT_NEE: c->cfg.nee = value ? 1 : 0; break;
+        case PT_OPT_NEE: if (value < 0 || value > 2) FAIL(c, PT_E_INVALID_ARG, "nee %d", value); c->cfg.nee = value; break;
         case PT_OPT_RNG_MODE: if (value != 0 && value != 1) FAIL(c, PT_E_INVALID_ARG, "rng_mode %d", value); c->cfg.rng_mode = value; break;
         case PT_OPT_TRAVERSAL_STATS: c->cfg.traversal_stats = value ? 1 : 0; break;
         case PT_OPT_STAGE_TIMING: if (value < 0 || value > 2) FAIL(c, PT_E_INVALID_ARG, "stage_timing %d", value); c->cfg.stage_timing = value; break;

@@ -27,7 +27,7 @@ struct RenderParams {
 
 struct Queues {
     float4* o[2];      // origin.xyz, birth index (bits)
-    float4* d[2];      // direction.xyz, flags (bits): bit0 = previous vertex was specular
+    float4* d[2];      // direction.xyz, flags: bit0 = previous vertex was specular; else, with multiple importance sampling, the sampled direction's density (low bit cleared)
     float4* T[2];      // throughput rgba
     float4* hit;       // t, triangle (bits), u, v
     float4* so;        // shadow origin.xyz, tmax
@@ -352,6 +352,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(DevScene sc, RenderPar
             const f3 o = xyz(ro), d = xyz(rd);
             birth = __float_as_uint(ro.w);
             const bool lastSpecular = (__float_as_uint(rd.w) & 1u) != 0u;
+            const float lastPdf = __uint_as_float(__float_as_uint(rd.w) & ~1u);   // density of the direction that led here (multiple importance sampling only)
             const f4 T = from4(q.T[cur][i]);
             const float4 hr = q.hit[i];
             const int32_t tri = __float_as_int(hr.y);
@@ -374,6 +375,18 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(DevScene sc, RenderPar
                 const float index = m2.y, roughness = m2.z;
                 if (m1.x > 0.0f || m1.y > 0.0f || m1.z > 0.0f) {   // shade.glsl:366-370
                     if (!rp.nee || lastSpecular) { add = T * from4(m1); addIt = true; }
+                    else if (rp.nee == 2) {
+                        // reached by sampling the BRDF at a vertex that also sampled the lights: balance heuristic
+                        // against the density the light sampling has for this very point
+                        const f3 ng = cross3(xyz(sc.tri_hot[3 * (size_t)tri + 1]), xyz(sc.tri_hot[3 * (size_t)tri + 2]));
+                        const float cosy = fabsf(dot3(d, ng)) / sqrtf(dot3(ng, ng));
+                        const float dist2 = hr.x * hr.x;
+                        if (cosy > 0.0f && dist2 > 0.0f) {
+                            const float pl = dist2 / (cosy * sc.light_total);
+                            add = (T * from4(m1)) * (lastPdf / (lastPdf + pl));
+                            addIt = true;
+                        }
+                    }
                 } else {
                     const float4 c0 = sc.tri_cold[3 * (size_t)tri], c1 = sc.tri_cold[3 * (size_t)tri + 1], c2 = sc.tri_cold[3 * (size_t)tri + 2];
                     const float hu = hr.z, hv = hr.w;
@@ -440,6 +453,10 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(DevScene sc, RenderPar
                                 const float geom = cosx * cosy * sc.light_total / dist2;
                                 const int32_t lm = __float_as_int(l1.w);
                                 sC = (T * brdf) * from4(sc.mats[3 * lm + 1]) * geom;
+                                if (rp.nee == 2) {   // balance heuristic against the BRDF sampling's density for this direction
+                                    const float pl = dist2 / (cosy * sc.light_total);
+                                    sC = sC * (pl / (pl + clamp01(cosx) * PT_INVPI));
+                                }
                                 sO = hitP + wn * PT_EPSILON;
                                 sD = wn;
                                 sTmax = dl * 0.999f;
@@ -460,6 +477,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(DevScene sc, RenderPar
                             newO = hitP + bounce * PT_EPSILON;
                             newD = bounce;
                             newFlags = (type != 0) ? 1u : 0u;
+                            if (type == 0 && rp.nee == 2) newFlags = __float_as_uint(clamp01(dot3(normal, bounce)) * PT_INVPI) & ~1u;
                             survive = !rp.last_bounce;
                         }
                     }

@@ -404,7 +404,7 @@ def test_context_lifecycle(pa, bundled, cornell):
     wf.close()
 
 
-@pytest.mark.parametrize("nee,rng_mode,bounces", [(0, 0, 10), (1, 0, 4), (1, 1, 4), (0, 1, 2)])
+@pytest.mark.parametrize("nee,rng_mode,bounces", [(0, 0, 10), (1, 0, 4), (1, 1, 4), (0, 1, 2), (2, 1, 5)])
 def test_radiance_bundled_256(pa, ob, bundled, wf_bundled, nee, rng_mode, bounces):
     """Bundled scene, every material type (diffuse/mirror/dielectric/metal), vs the oracle path tracer."""
     w, h, spp = 256, 256, 3
@@ -431,21 +431,51 @@ def test_radiance_bundled_256(pa, ob, bundled, wf_bundled, nee, rng_mode, bounce
     wf.set_option(2, 0)
 
 
-def test_radiance_cornell_nee(pa, ob, cornell):
-    """Cornell box (quads, negative indices, no normals -> flat-normal fallback), NEE on."""
+@pytest.mark.parametrize("nee", [1, 2])
+def test_radiance_cornell_nee(pa, ob, cornell, nee):
+    """Cornell box (quads, negative indices, no normals -> flat-normal fallback), NEE on, without and with multiple
+    importance sampling."""
     w, h, spp = 128, 128, 4
-    wf = make_wf(pa, cornell, nee=True, rng_mode=1)
+    wf = make_wf(pa, cornell, nee=nee, rng_mode=1)
     wf.allocate(w, h, sky=(0, 0, 0, 1))
     fs, _ = cornell.camera((0, 1, 3.4), (0, 1, 0), w, h, use_scene=True, frames=1, samples=1)
     wf.invoke(fs, spp=spp, max_bounces=5)
     img = wf.read_image()
-    osum, _ = cornell.render(ob.render_state(w, h, sky=(0, 0, 0, 1)), fs, ob.path_config(5, 1, 1), spp, threads=8)
+    osum, _ = cornell.render(ob.render_state(w, h, sky=(0, 0, 0, 1)), fs, ob.path_config(5, nee, 1), spp, threads=8)
     oimg = osum / np.float32(spp)
     assert oimg[..., :3].mean() > 0.01
     finite = np.isfinite(oimg).all(axis=2)
     assert np.array_equal(np.isfinite(img).all(axis=2), finite)
     assert rel_rmse(img[finite][:, :3], oimg[finite][:, :3]) <= RADIANCE_RELRMSE_TOL
+    assert np.array_equal(bits(img)[finite], bits(oimg)[finite])
     wf.close()
+
+
+def test_three_estimators_have_one_expectation(pa, cornell):
+    """The reference's estimator (emitters counted when a path runs into them, shade.glsl:366-370), next-event
+    estimation, and the two combined by multiple importance sampling must converge to the same image.  Cornell box,
+    64x64, 65,536 samples per pixel each, compared on 8x8-pixel blocks.  Tolerances (stated here, statistical): block
+    median of the relative difference <= 1.5 %, whole-image mean <= 1 %; plain light sampling is left out of the mean
+    check because next to the two-sided lamp its 1/distance^2 weights have a heavy tail that 64k samples do not average
+    out (which is what the combination is for)."""
+    w = h = 64
+    spp = 65536
+    fs, _ = cornell.camera((0, 1, 3.4), (0, 1, 0), w, h, use_scene=True, frames=1, samples=1)
+    imgs = {}
+    for nee in (0, 1, 2):
+        wf = make_wf(pa, cornell, nee=nee, rng_mode=1)
+        wf.allocate(w, h, sky=(0, 0, 0, 1))
+        wf.invoke(fs, spp=spp, max_bounces=8)
+        imgs[nee] = wf.read_image()[..., :3].astype(np.float64)
+        assert np.isfinite(imgs[nee]).all()
+        wf.close()
+    blocks = {k: v.reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3, 4)) for k, v in imgs.items()}
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        rel = np.abs(blocks[a] - blocks[b]) / np.maximum(blocks[a], 1e-6)
+        print(f"estimators {a} vs {b}: block median {np.median(rel):.4f}, p90 {np.percentile(rel, 90):.4f}, "
+              f"means {imgs[a].mean():.5f} {imgs[b].mean():.5f}")
+        assert np.median(rel) <= 0.015
+    assert abs(imgs[0].mean() - imgs[2].mean()) <= 0.01 * imgs[0].mean()
 
 
 def test_traversal_counters_match_oracle(pa, ob, bundled):

@@ -155,6 +155,29 @@ def test_cornell_flat_normal_fallback(cornell):
     assert ((n3 < 1e-6) | (np.abs(n3 - 1) < 1e-5)).all() and (n3 < 1e-6).sum() == 18
 
 
+def test_estimators_agree_in_expectation(ob, cornell):
+    """Next-event estimation is not in the reference; what ties it to the reference is that it estimates the same image
+    as the reference's own estimator (emitters counted only when a path hits them, shade.glsl:366-370).  Cornell box,
+    32x32, 1024 samples per pixel, on 8x8-pixel blocks: median relative difference between any two of {reference
+    estimator, light sampling, both with multiple importance sampling} <= 8 % (the noise of this sample count; the GPU
+    suite repeats it with 64k samples and a 1.5 % bound), mean of the combined estimator within 3 % of the reference's."""
+    w = h = 32
+    spp = 1024
+    fs, _ = cornell.camera((0, 1, 3.4), (0, 1, 0), w, h, use_scene=True, frames=1, samples=1)
+    rs = ob.render_state(w, h, sky=(0, 0, 0, 1))
+    imgs = {}
+    for nee in (0, 1, 2):
+        osum, st = cornell.render(rs, fs, ob.path_config(6, nee, 1), spp, threads=8)
+        assert np.isfinite(osum).all()
+        assert (st["shadow_rays"] > 0) == (nee != 0)
+        imgs[nee] = osum[..., :3].astype(np.float64) / spp
+    blocks = {k: v.reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3, 4)) for k, v in imgs.items()}
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        rel = np.abs(blocks[a] - blocks[b]) / np.maximum(blocks[a], 1e-6)
+        assert np.median(rel) <= 0.08, (a, b, np.median(rel))
+    assert abs(imgs[0].mean() - imgs[2].mean()) <= 0.03 * imgs[0].mean()
+
+
 def test_deterministic_elementary_functions(ob):
     x = np.linspace(0, 2 * np.pi, 200001).astype(np.float32)
     assert np.abs(ob.det_math("sin", x) - np.sin(x.astype(np.float64))).max() < 3e-7
