@@ -5,6 +5,22 @@
 #include "pt_device.hpp"
 
 #define PT_BLOCK 256
+
+// Queue traffic is streamed once per stage: non-temporal accesses keep it from displacing the tree and the triangles in L2.
+#ifdef PT_NO_NT
+__device__ __forceinline__ float4 ntLoad(const float4* p) { return *p; }
+__device__ __forceinline__ void ntStore(float4* p, float4 v) { *p = v; }
+#else
+typedef float pt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ntLoad(const float4* p) {
+    const pt_v4f v = __builtin_nontemporal_load((const pt_v4f*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void ntStore(float4* p, float4 v) {
+    const pt_v4f w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (pt_v4f*)p);
+}
+#endif
 #ifndef PT_SHADE_BLOCK
 #define PT_SHADE_BLOCK 768
 #endif
@@ -72,8 +88,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_generate(RenderParams rp, Queues q
     }
     const uint32_t out = DENSE ? k : waveAppend(valid, &ctl->count[0]);
     if (valid) {
-        q.o[0][out] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(k));
-        q.d[0][out] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(1u));
+        ntStore(&q.o[0][out], make_float4(origin.x, origin.y, origin.z, __uint_as_float(k)));
+        ntStore(&q.d[0][out], make_float4(dir.x, dir.y, dir.z, __uint_as_float(1u)));
         // the throughput of a fresh path is (1,1,1,1) (generate.glsl:199): shade knows that at bounce 0, so it is not stored
     }
 }
@@ -87,13 +103,13 @@ struct ExtendSource {
     const float4* d;
     float4* hit;
     __device__ __forceinline__ void load(uint32_t i, f3* ro, f3* rd, float* tlimit) const {
-        const float4 a = o[i], b = d[i];
+        const float4 a = ntLoad(&o[i]), b = ntLoad(&d[i]);
         *ro = xyz(a);
         *rd = xyz(b);
         *tlimit = PT_INF;
     }
     __device__ __forceinline__ void store(uint32_t i, const HitRec& h, bool) const {
-        hit[i] = make_float4(h.t, __int_as_float(h.tri), h.u, h.v);
+        ntStore(&hit[i], make_float4(h.t, __int_as_float(h.tri), h.u, h.v));
     }
 };
 
@@ -160,7 +176,7 @@ struct ConnectSource {
     const float4* sc;
     float4* plane;
     __device__ __forceinline__ void load(uint32_t i, f3* ro, f3* rd, float* tlimit) const {
-        const float4 a = so[i], b = sd[i];
+        const float4 a = ntLoad(&so[i]), b = ntLoad(&sd[i]);
         *ro = xyz(a);
         *rd = xyz(b);
         *tlimit = a.w;
@@ -353,13 +369,13 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DevSce
         float sTmax = 0.0f;
         f4 sC = mk4(0, 0, 0, 0);
         if (active) {
-            const float4 ro = q.o[cur][i], rd = q.d[cur][i];
+            const float4 ro = ntLoad(&q.o[cur][i]), rd = ntLoad(&q.d[cur][i]);
             const f3 o = xyz(ro), d = xyz(rd);
             birth = __float_as_uint(ro.w);
             const bool lastSpecular = (__float_as_uint(rd.w) & 1u) != 0u;
             const float lastPdf = __uint_as_float(__float_as_uint(rd.w) & ~1u);   // density of the direction that led here (multiple importance sampling only)
-            const f4 T = rp.bounce == 0 ? mk4(1.0f, 1.0f, 1.0f, 1.0f) : from4(q.T[cur][i]);
-            const float4 hr = q.hit[i];
+            const f4 T = rp.bounce == 0 ? mk4(1.0f, 1.0f, 1.0f, 1.0f) : from4(ntLoad(&q.T[cur][i]));
+            const float4 hr = ntLoad(&q.hit[i]);
             const int32_t tri = __float_as_int(hr.y);
             const uint32_t sample = birth / rp.slots;
             const uint32_t slot = birth - sample * rp.slots;
@@ -493,14 +509,14 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DevSce
         uint32_t slotOut, sOut;
         blockAppend2(survive, shadow, &ctl->count[nxt], &ctl->shadow_count, s_append[it & 1u], &slotOut, &sOut);
         if (survive) {
-            q.o[nxt][slotOut] = make_float4(newO.x, newO.y, newO.z, __uint_as_float(birth));
-            q.d[nxt][slotOut] = make_float4(newD.x, newD.y, newD.z, __uint_as_float(newFlags));
-            q.T[nxt][slotOut] = to4(newT);
+            ntStore(&q.o[nxt][slotOut], make_float4(newO.x, newO.y, newO.z, __uint_as_float(birth)));
+            ntStore(&q.d[nxt][slotOut], make_float4(newD.x, newD.y, newD.z, __uint_as_float(newFlags)));
+            ntStore(&q.T[nxt][slotOut], to4(newT));
         }
         if (shadow) {
-            q.so[sOut] = make_float4(sO.x, sO.y, sO.z, sTmax);
-            q.sd[sOut] = make_float4(sD.x, sD.y, sD.z, __uint_as_float(birth));
-            q.sc[sOut] = to4(sC);
+            ntStore(&q.so[sOut], make_float4(sO.x, sO.y, sO.z, sTmax));
+            ntStore(&q.sd[sOut], make_float4(sD.x, sD.y, sD.z, __uint_as_float(birth)));
+            ntStore(&q.sc[sOut], to4(sC));
         }
     }
 }
