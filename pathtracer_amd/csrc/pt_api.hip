@@ -479,8 +479,10 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
         const uint32_t total = c->slots * ns;
         rp.frames0 = (uint32_t)fs.frames + s0;
         rp.samples = ns;
-        HIPCHECK(c, hipMemsetAsync(c->q.plane, 0, (size_t)total * sizeof(float4), c->stream));
         const bool dense = (c->width % 8 == 0) && (c->height % 8 == 0);
+        // dense batches: every slot is a path, and shade of bounce 0 stores each path's first value itself
+        rp.plane_fresh = (dense && !generate_only) ? 1 : 0;
+        if (!rp.plane_fresh) HIPCHECK(c, hipMemsetAsync(c->q.plane, 0, (size_t)total * sizeof(float4), c->stream));
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, dense ? total : 0u, 0ull);
         {
             StageTimer t(c, 0);

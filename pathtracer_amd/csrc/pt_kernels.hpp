@@ -38,6 +38,7 @@ struct RenderParams {
     uint32_t samples;          // samples in this batch
     int32_t rank, world;
     int32_t rng_mode, nee;
+    int32_t plane_fresh;       // the batch's planes were not cleared: shade of bounce 0 stores every path's first value
     int32_t bounce, last_bounce;
 };
 
@@ -504,7 +505,8 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DevSce
                     }
                 }
             }
-            if (addIt) q.plane[birth] = to4(from4(q.plane[birth]) + add);
+            if (rp.plane_fresh && rp.bounce == 0) ntStore(&q.plane[birth], to4(add));   // every path passes here once: no clear, no read
+            else if (addIt) q.plane[birth] = to4(from4(q.plane[birth]) + add);
         }
         uint32_t slotOut, sOut;
         blockAppend2(survive, shadow, &ctl->count[nxt], &ctl->shadow_count, s_append[it & 1u], &slotOut, &sOut);
