@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--bounces", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0, help="samples traced concurrently (0 = automatic)")
     ap.add_argument("--blocks", type=int, default=-1, help="resident traversal blocks per CU (-1 = the library's choice, 0 = as many as fit)")
+    ap.add_argument("--refill-primary", type=int, default=0, help="idle lanes a traversal wave collects before fetching camera rays (0 = the library's choice)")
+    ap.add_argument("--refill-bounce", type=int, default=0, help="the same for bounce and shadow rays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only for rehearsing N > 1 on a single GPU")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
@@ -146,6 +148,10 @@ def main():
     wf.upload_scene(mats, tris, nodes)
     if args.blocks >= 0:
         wf.set_option(6, args.blocks)
+    if args.refill_primary:
+        wf.set_option(7, args.refill_primary)
+    if args.refill_bounce:
+        wf.set_option(8, args.refill_bounce)
     wf.allocate(w, h)
     cam, pos, tgt = camera_for(args.workload, w, h, wf)
     fs = cam.frame_state(pos, tgt, frames=1, samples=0)

@@ -57,6 +57,9 @@ struct pt_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool render_pending = false;
     pt_stats host_stats{};
+    // idle lanes a traversal wave collects before it fetches new rays: camera rays of a tile finish together, so waiting for
+    // most of the wave costs little and saves refills; scattered rays finish at very different times
+    int refill_primary = 48, refill_bounce = 32;
     int grid_extend = 0, grid_connect = 0, grid_shade = 0, grid_special = 0, fit_extend = 1, fit_connect = 1;
 };
 
@@ -275,6 +278,8 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
             c->grid_extend = c->num_cu * std::min(value ? value : 7, c->fit_extend);
             c->grid_connect = c->num_cu * std::min(value ? value : 7, c->fit_connect);
             break;
+        case PT_OPT_REFILL_PRIMARY: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_primary = value; break;
+        case PT_OPT_REFILL_BOUNCE: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_bounce = value; break;
         case PT_OPT_SAMPLES_PER_BATCH: if (value < 0) FAIL(c, PT_E_INVALID_ARG, "samples_per_batch %d", value); c->cfg.samples_per_batch = value; break;
         default: FAIL(c, PT_E_INVALID_ARG, "unknown option %d", key);
     }
@@ -441,13 +446,13 @@ int pt_reset_accumulation(pt_ctx* c) {
 }
 
 // The wide pass over the queue, then the two-wide pass over the rays it set aside (normally none).
-static void launchExtend(pt_ctx* c, bool stats, int cur) {
+static void launchExtend(pt_ctx* c, bool stats, int cur, uint32_t refillMin) {
     if (stats) {
-        hipLaunchKernelGGL((k_extend<true, false>), dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
-        hipLaunchKernelGGL((k_extend<true, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
+        hipLaunchKernelGGL((k_extend<true, false>), dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
+        hipLaunchKernelGGL((k_extend<true, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
     } else {
-        hipLaunchKernelGGL((k_extend<false, false>), dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
-        hipLaunchKernelGGL((k_extend<false, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur);
+        hipLaunchKernelGGL((k_extend<false, false>), dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
+        hipLaunchKernelGGL((k_extend<false, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
     }
 }
 
@@ -497,7 +502,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             rp.last_bounce = (b == max_bounces - 1) ? 1 : 0;
             {
                 StageTimer t(c, 1);
-                launchExtend(c, stats, cur);
+                launchExtend(c, stats, cur, (uint32_t)(b == 0 ? c->refill_primary : c->refill_bounce));
                 c->host_stats.extend_launches++;
             }
             {
@@ -508,11 +513,11 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             if (rp.nee && c->sc.n_lights > 0) {
                 StageTimer t(c, 3);
                 if (stats) {
-                    hipLaunchKernelGGL((k_connect<true, false>), dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
-                    hipLaunchKernelGGL((k_connect<true, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
+                    hipLaunchKernelGGL((k_connect<true, false>), dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
+                    hipLaunchKernelGGL((k_connect<true, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
                 } else {
-                    hipLaunchKernelGGL((k_connect<false, false>), dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
-                    hipLaunchKernelGGL((k_connect<false, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl);
+                    hipLaunchKernelGGL((k_connect<false, false>), dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
+                    hipLaunchKernelGGL((k_connect<false, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
                 }
                 c->host_stats.connect_launches++;
             }
@@ -697,7 +702,7 @@ int pt_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t iters, float
     for (int it = 0; it < iters + 1; it++) {   // the first launch warms caches and is not counted
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, (uint32_t)n, 0ull);
         HIPCHECK(c, hipEventRecord(a, c->stream));
-        launchExtend(c, stats, 0);
+        launchExtend(c, stats, 0, (uint32_t)c->refill_bounce);
         HIPCHECK(c, hipEventRecord(b, c->stream));
         HIPCHECK(c, hipStreamSynchronize(c->stream));
         float ms = 0.0f;

@@ -359,7 +359,7 @@ static inline uint32_t packLeaf(int32_t first, int32_t count, uint32_t bigIndex)
 
 template <bool ANYHIT, bool STATS, bool WIDE, class Source>
 __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, unsigned long long* leafq, const Source& src,
-                                             uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched,
+                                             uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched, uint32_t refillMin,
                                              uint32_t* specialCount = nullptr, uint32_t* specialList = nullptr) {
     // sched[0..2] (STATS builds): wave iterations spent on interior steps, leaf steps, retire/refill
     const uint32_t lane = laneId();
@@ -424,11 +424,11 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
 
     for (;;) {
         // ---- retire finished rays and hand the idle lanes the next rays: when nothing is in flight, or when
-        //      PT_REFILL_MIN lanes are idle and rays remain to be handed out
+        //      refillMin lanes are idle and rays remain to be handed out
         {
             const uint32_t nActive = (uint32_t)__popcll(__ballot(cur != 0u));
             const bool moreRays = !(exhausted && rangeLo == rangeHi);
-            if (nActive == 0u || (moreRays && 64u - nActive >= PT_REFILL_MIN)) {
+            if (nActive == 0u || (moreRays && 64u - nActive >= refillMin)) {
                 if (STATS) sched[2]++;
                 if (rayIdx != PT_NO_RAY && cur == 0u) {
                     HitRec h;
@@ -484,7 +484,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             const unsigned long long interiorMask = __ballot((int32_t)cur > 0);
             const uint32_t nLeaf = (uint32_t)__popcll(__ballot((int32_t)cur < 0));
             if (interiorMask == 0ull || nLeaf >= PT_LEAF_BATCH) break;
-            if (refillable && 64u - (uint32_t)__popcll(interiorMask) - nLeaf >= PT_REFILL_MIN) break;
+            if (refillable && 64u - (uint32_t)__popcll(interiorMask) - nLeaf >= refillMin) break;
             if (STATS) sched[0]++;
             if (WIDE) {
                 if ((int32_t)cur > 0) {
@@ -599,7 +599,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             const uint32_t nLeaf = (uint32_t)__popcll(leafMask);
             const uint32_t nInterior = (uint32_t)__popcll(__ballot((int32_t)cur > 0));
             if (nInterior != 0u && nLeaf < PT_LEAF_BATCH) break;
-            if (refillable && 64u - nInterior - nLeaf >= PT_REFILL_MIN) break;
+            if (refillable && 64u - nInterior - nLeaf >= refillMin) break;
             if (STATS) sched[1]++;
             unsigned long long* const resKey = leafq;                       // [64] best (distance bits, triangle) per owner
             float2* const resUv = (float2*)(leafq + 64);                    // [64] its barycentrics

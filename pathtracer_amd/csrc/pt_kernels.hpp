@@ -126,7 +126,7 @@ struct ListSource {
 // SPECIAL = false: the wide traversal of every ray of the queue; rays it cannot take are listed in q.special.
 // SPECIAL = true: the two-wide traversal of the listed rays (launched right after, usually with nothing to do).
 template <bool STATS, bool SPECIAL>
-__global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur) {
+__global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
@@ -152,9 +152,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene
         ListSource<ExtendSource> ls;
         ls.inner = src;
         ls.list = q.special;
-        traverseWave<false, STATS, false>(sc, n, &ctl->cursor_special, lstack, leafq, ls, &steps, &tris, &overflow, sched);
+        traverseWave<false, STATS, false>(sc, n, &ctl->cursor_special, lstack, leafq, ls, &steps, &tris, &overflow, sched, refillMin);
     } else {
-        traverseWave<false, STATS, true>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, &ctl->special_extend, q.special);
+        traverseWave<false, STATS, true>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_extend, q.special);
     }
     if (STATS) {
         waveAdd64(&ctl->extend_steps, steps);
@@ -191,7 +191,7 @@ struct ConnectSource {
 };
 
 template <bool STATS, bool SPECIAL>
-__global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScene sc, Queues q, Ctl* ctl) {
+__global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScene sc, Queues q, Ctl* ctl, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
@@ -211,9 +211,9 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScen
         ListSource<ConnectSource> ls;
         ls.inner = src;
         ls.list = q.special;
-        traverseWave<true, STATS, false>(sc, n, &ctl->cursor_special, lstack, leafq, ls, &steps, &tris, &overflow, sched);
+        traverseWave<true, STATS, false>(sc, n, &ctl->cursor_special, lstack, leafq, ls, &steps, &tris, &overflow, sched, refillMin);
     } else {
-        traverseWave<true, STATS, true>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, &ctl->special_connect, q.special);
+        traverseWave<true, STATS, true>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_connect, q.special);
     }
     if (STATS) {
         waveAdd64(&ctl->shadow_steps, steps);
@@ -573,6 +573,7 @@ struct TraceSource {
 // list in `special` and its length in ctl->special_extend.
 template <bool ANYHIT, bool SPECIAL>
 __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src, int n, Ctl* ctl, uint32_t* special) {
+    const uint32_t refillMin = PT_REFILL_MIN;   // no shared cursor here: every wave traces its own 64 rays and never refills
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
@@ -583,9 +584,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src
         ListSource<TraceSource> ls;
         ls.inner = src;
         ls.list = special;
-        traverseWave<ANYHIT, false, false>(sc, ctl->special_extend, nullptr, lstack, leafq, ls, &steps, &tris, &overflow, sched);
+        traverseWave<ANYHIT, false, false>(sc, ctl->special_extend, nullptr, lstack, leafq, ls, &steps, &tris, &overflow, sched, refillMin);
     } else {
-        traverseWave<ANYHIT, false, true>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, &ctl->special_extend, special);
+        traverseWave<ANYHIT, false, true>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_extend, special);
     }
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
 }

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--stats", action="store_true")
     ap.add_argument("--blocks", type=int, default=0, help="resident traversal blocks per CU (0 = as many as fit)")
+    ap.add_argument("--refill", type=int, default=0, help="idle lanes a wave collects before fetching rays (0 = the library's choice for bounce rays)")
     ap.add_argument("--coherent", action="store_true", help="primary camera rays instead of bounce rays")
     ap.add_argument("--sort", type=int, default=0, help="experiment: order the rays by a Morton key of the origin with this many bits per axis (+ direction octant)")
     args = ap.parse_args()
@@ -50,6 +51,8 @@ def main():
     wf = pa.Wavefront(traversal_stats=args.stats)
     if args.blocks:
         wf.set_option(6, args.blocks)
+    if args.refill:
+        wf.set_option(8, args.refill)
     wf.upload_scene(mats, tris, nodes)
     rng = np.random.RandomState(1)
     n = args.rays
