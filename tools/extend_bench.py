@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=0, help="resident traversal blocks per CU (0 = as many as fit)")
     ap.add_argument("--refill", type=int, default=0, help="idle lanes a wave collects before fetching rays (0 = the library's choice for bounce rays)")
     ap.add_argument("--coherent", action="store_true", help="primary camera rays instead of bounce rays")
+    ap.add_argument("--spp", type=int, default=1, help="with --coherent: this many samples of every pixel")
     ap.add_argument("--sort", type=int, default=0, help="experiment: order the rays by a Morton key of the origin with this many bits per axis (+ direction octant)")
     args = ap.parse_args()
 
@@ -66,7 +67,11 @@ def main():
         wf.allocate(w, h)
         pos, tgt = ((0, 2, 15), (0, 3, 0)) if args.scene == "bundled" else ((0, 0, 120), (0, 0, 0))
         fs = Camera(w, h).frame_state(pos, tgt, frames=1)
-        rays, _ = wf.generate_rays(fs, w * h)
+        parts = []
+        for k in range(args.spp):   # sample-major, as a render call's first extend launch sees them
+            fs["frames"] = 1 + k
+            parts.append(wf.generate_rays(fs, w * h)[0])
+        rays = np.concatenate(parts, 0)
     else:
         o = rng.uniform(lo, hi, (n * 2, 3)).astype(np.float32)
         first = np.concatenate([o, unit(n * 2)], 1)
