@@ -10,8 +10,12 @@
 #include <type_traits>
 
 #define PT_WAVE 64
-#define PT_STACK_LDS 8       // traversal stack entries (8 bytes each) kept in LDS per lane
-#define PT_STACK_SPILL 88    // further entries in per-lane scratch
+#ifndef PT_STACK_LDS
+#define PT_STACK_LDS 10      // traversal stack entries (8 bytes each) kept in LDS per lane: the most that leaves room for 6 blocks per CU
+#endif
+#ifndef PT_STACK_SPILL
+#define PT_STACK_SPILL 86    // further entries in per-lane scratch
+#endif
 #define PT_LEAFQ_WORDS 160   // 8-byte words of LDS per wave for the leaf phase: 64 result keys, 64 (u, v), 64 owner lanes
 #define PT_STACK_TOTAL (PT_STACK_LDS + PT_STACK_SPILL)
 #define PT_EPSILON 0.00001f  // extend.glsl:4 / shade.glsl:4
@@ -548,7 +552,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     // survivors beyond the nearest: pushed farthest first (sorted: k3 present implies k2, k2 implies k1)
                     if (k1 != PT_KEY_MISS) {
                         const int np = 1 + (k2 != PT_KEY_MISS ? 1 : 0) + (k3 != PT_KEY_MISS ? 1 : 0);
-                        if (sp + 3 <= PT_STACK_LDS) {
+                        if (sp + np <= PT_STACK_LDS) {
                             uint2* const at = mystack + sp * PT_WAVE;
                             if (np == 3) at[0] = make_uint2(e3, k3 & ~3u);
                             if (np >= 2) at[(np - 2) * PT_WAVE] = make_uint2(e2, k2 & ~3u);
