@@ -61,7 +61,7 @@ typedef struct pt_stats {
     uint64_t extend_rays;       /* rays traced by extend (primary + bounce) */
     uint64_t shadow_rays;       /* rays traced by connect */
     uint64_t extend_steps;      /* node records fetched in extend: quad records, plus pair records for the rays
-                                   of the two-wide pass   (traversal_stats) */
+                                   on the two-wide walk   (traversal_stats) */
     uint64_t extend_tris;       /* triangle tests in extend      (traversal_stats) */
     uint64_t shadow_steps;
     uint64_t shadow_tris;
@@ -73,7 +73,7 @@ typedef struct pt_stats {
     /* extend stage, traversal_stats only: iterations a wave spent on interior steps, on leaf (triangle) steps and on
      * retiring/refilling lanes; extend_steps / (64 * sched_interior) is the lane utilisation of the interior loop */
     uint64_t sched_interior, sched_leaf, sched_refill;
-    uint64_t special_rays;      /* rays (extend + connect) that took the two-wide pass: zero/denormal/non-finite components */
+    uint64_t special_rays;      /* rays (extend + connect) that took the two-wide walk: zero/denormal/non-finite components */
 } pt_stats;
 
 /* ---- lifetime --------------------------------------------------------------

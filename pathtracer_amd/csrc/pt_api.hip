@@ -60,7 +60,7 @@ struct pt_ctx {
     // idle lanes a traversal wave collects before it fetches new rays: camera rays of a tile finish together, so waiting for
     // most of the wave costs little and saves refills; scattered rays finish at very different times
     int refill_primary = 48, refill_bounce = 32;
-    int grid_extend = 0, grid_connect = 0, grid_shade = 0, grid_special = 0, fit_extend = 1, fit_connect = 1;
+    int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
 };
 
 #define FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); if (ctx) (ctx)->err = _b; else g_err = _b; return (code); } while (0)
@@ -94,12 +94,6 @@ int allocQueues(pt_ctx* c, uint32_t capacity) {
         HIPCHECK(c, hipMalloc(&p, (size_t)capacity * sizeof(float4)));
         c->qmem.push_back(p);
         *col = (float4*)p;
-    }
-    {
-        void* p = nullptr;
-        HIPCHECK(c, hipMalloc(&p, (size_t)capacity * sizeof(uint32_t)));
-        c->qmem.push_back(p);
-        c->q.special = (uint32_t*)p;
     }
     c->capacity = capacity;
     return PT_OK;
@@ -235,17 +229,16 @@ int pt_create(const pt_config* cfg, pt_ctx** out) {
     }
     c->num_cu = prop.multiProcessorCount;
     int perCu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_extend<false, false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_extend<false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
     c->fit_extend = perCu;
     perCu = std::min(perCu, 7);   // more resident waves than this thrash the caches on incoherent rays
     c->grid_extend = c->num_cu * perCu;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_connect<false, false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_connect<false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
     c->fit_connect = perCu;
     perCu = std::min(perCu, 7);
     c->grid_connect = c->num_cu * perCu;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_shade, PT_SHADE_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 2;
     c->grid_shade = c->num_cu * perCu;   // one resident round: the kernel strides over the queue
-    c->grid_special = c->num_cu * 2;
     *out = c;
     return PT_OK;
 }
@@ -448,11 +441,9 @@ int pt_reset_accumulation(pt_ctx* c) {
 // The wide pass over the queue, then the two-wide pass over the rays it set aside (normally none).
 static void launchExtend(pt_ctx* c, bool stats, int cur, uint32_t refillMin) {
     if (stats) {
-        hipLaunchKernelGGL((k_extend<true, false>), dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
-        hipLaunchKernelGGL((k_extend<true, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
+        hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
     } else {
-        hipLaunchKernelGGL((k_extend<false, false>), dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
-        hipLaunchKernelGGL((k_extend<false, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
+        hipLaunchKernelGGL(k_extend<false>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
     }
 }
 
@@ -513,11 +504,9 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             if (rp.nee && c->sc.n_lights > 0) {
                 StageTimer t(c, 3);
                 if (stats) {
-                    hipLaunchKernelGGL((k_connect<true, false>), dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
-                    hipLaunchKernelGGL((k_connect<true, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
+                    hipLaunchKernelGGL(k_connect<true>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
                 } else {
-                    hipLaunchKernelGGL((k_connect<false, false>), dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
-                    hipLaunchKernelGGL((k_connect<false, true>), dim3(c->grid_special), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
+                    hipLaunchKernelGGL(k_connect<false>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
                 }
                 c->host_stats.connect_launches++;
             }
@@ -601,23 +590,20 @@ static int traceCommon(pt_ctx* c, bool anyhit, const float* o_d, const float* tm
     if (n == 0) return PT_OK;
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     float *d_rays = nullptr, *d_tmax = nullptr, *d_t = nullptr, *d_uv = nullptr;
-    uint32_t* d_special = nullptr;
     int32_t* d_tri = nullptr;
     uint8_t* d_occ = nullptr;
     int rc = PT_OK;
-    auto cleanup = [&]() { (void)hipFree(d_rays); (void)hipFree(d_tmax); (void)hipFree(d_t); (void)hipFree(d_uv); (void)hipFree(d_tri); (void)hipFree(d_occ); (void)hipFree(d_special); };
+    auto cleanup = [&]() { (void)hipFree(d_rays); (void)hipFree(d_tmax); (void)hipFree(d_t); (void)hipFree(d_uv); (void)hipFree(d_tri); (void)hipFree(d_occ); };
 #define TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); FAIL(c, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s", #call, hipGetErrorString(_e)); } } while (0)
     TRY(hipMalloc((void**)&d_rays, (size_t)n * 24));
     TRY(hipMemcpyAsync(d_rays, o_d, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
-    TRY(hipMalloc((void**)&d_special, (size_t)n * 4));
     hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, 0ull);
     if (anyhit) {
         TRY(hipMalloc((void**)&d_tmax, (size_t)n * 4));
         TRY(hipMalloc((void**)&d_occ, (size_t)n));
         TRY(hipMemcpyAsync(d_tmax, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
         TraceSource src{d_rays, d_tmax, nullptr, nullptr, nullptr, d_occ};
-        hipLaunchKernelGGL((k_trace<true, false>), dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl, d_special);
-        hipLaunchKernelGGL((k_trace<true, true>), dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl, d_special);
+        hipLaunchKernelGGL(k_trace<true>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl);
         TRY(hipGetLastError());
         TRY(hipMemcpyAsync(occ, d_occ, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     } else {
@@ -625,8 +611,7 @@ static int traceCommon(pt_ctx* c, bool anyhit, const float* o_d, const float* tm
         TRY(hipMalloc((void**)&d_t, (size_t)n * 4));
         if (uv) TRY(hipMalloc((void**)&d_uv, (size_t)n * 8));
         TraceSource src{d_rays, nullptr, d_tri, d_t, d_uv, nullptr};
-        hipLaunchKernelGGL((k_trace<false, false>), dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl, d_special);
-        hipLaunchKernelGGL((k_trace<false, true>), dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl, d_special);
+        hipLaunchKernelGGL(k_trace<false>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl);
         TRY(hipGetLastError());
         if (tri) TRY(hipMemcpyAsync(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         if (t) TRY(hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));

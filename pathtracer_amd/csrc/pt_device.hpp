@@ -83,12 +83,9 @@ struct Ctl {
     uint32_t shadow_count;    // rays in the shadow queue
     uint32_t cursor_extend;   // next unclaimed ray of the running extend launch
     uint32_t cursor_connect;
-    uint32_t special_extend;  // rays the wide traversal handed to the two-wide one (see traverseWave), per stage
-    uint32_t special_connect;
-    uint32_t cursor_special;
     unsigned long long paths, extend_rays, shadow_rays, extend_steps, extend_tris, shadow_steps, shadow_tris, stack_overflows;
     unsigned long long sched_interior, sched_leaf, sched_refill;   // wave iterations by kind, extend stage, instrumented builds
-    unsigned long long special_rays;                               // rays handed to the two-wide passes
+    unsigned long long special_rays;                               // rays that took the two-wide, NaN-rejecting walk
 };
 
 // ------------------------------------------------ deterministic elementary fns
@@ -298,7 +295,7 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 //   (first, count) instead.
 //   Closest-hit ties go to the smaller triangle index.
 //
-// Wide traversal (WIDE = true; every ray whose slab distances cannot be NaN)
+// Wide traversal (every ray whose slab distances cannot be NaN)
 //
 //   The same walk over the tree with every other level skipped: an interior entry refers to a
 //   quad record, a step slab-tests its (up to four) boxes, drops the culled ones as above, visits
@@ -309,8 +306,9 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 //   Skipping a level is exact: for a ray without NaN slab distances a box that passes the slab test
 //   lies inside a parent that passes it too (subtraction and multiplication round monotonically),
 //   and the parent's entry distance is not larger, so the two-wide walk reaches the same leaves.
-//   A ray that can produce NaN (zero, denormal or non-finite components: raySpecial) is not
-//   traversed here: its index is appended to `specialList` and a two-wide launch follows.
+//   A ray that can produce NaN (zero, denormal or non-finite components: raySpecial) does not
+//   take this walk: its lane runs the two-wide, NaN-rejecting step over the pair records inside
+//   the same loop (such rays are a few in a hundred million, so the divergence costs nothing).
 //
 // Per-wave scheduling (free to change: it cannot alter any ray's result)
 //
@@ -361,10 +359,10 @@ static inline uint32_t packLeaf(int32_t first, int32_t count, uint32_t bigIndex)
 // reference, sign bit set = leaf whose remaining triangles are [leafJ, leafEnd).
 #define PT_KEY_MISS 0xFFFFFFFFu
 
-template <bool ANYHIT, bool STATS, bool WIDE, class Source>
+template <bool ANYHIT, bool STATS, class Source>
 __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, unsigned long long* leafq, const Source& src,
                                              uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched, uint32_t refillMin,
-                                             uint32_t* specialCount = nullptr, uint32_t* specialList = nullptr) {
+                                             unsigned long long* specialRays) {
     // sched[0..2] (STATS builds): wave iterations spent on interior steps, leaf steps, retire/refill
     const uint32_t lane = laneId();
     const uint32_t totalWaves = gridDim.x * (blockDim.x / PT_WAVE);
@@ -469,14 +467,12 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     cur = 0;
                     if (in) {
                         if (sc.root_count > 0) { cur = PT_LEAF_FLAG; leafJ = sc.root_left; leafEnd = sc.root_left + sc.root_count; }
-                        else cur = WIDE ? 1u : (uint32_t)sc.root_left;   // quad 0, or the node index of the root's left child
+                        else cur = special ? (uint32_t)sc.root_left : 1u;   // the node index of the root's left child (two-wide walk), or quad 0
                     }
                 }
-                if (WIDE) {
-                    // rays that can produce NaN slab distances go to the two-wide launch that follows
-                    const bool divert = rayIdx != PT_NO_RAY && (idleMask >> lane & 1ull) && special;
-                    const uint32_t at = waveAppend(divert, specialCount);
-                    if (divert) { specialList[at] = rayIdx; rayIdx = PT_NO_RAY; cur = 0; }
+                {
+                    const unsigned long long sm = __ballot(rayIdx != PT_NO_RAY && (idleMask >> lane & 1ull) && special);
+                    if (sm != 0ull && lane == 0u) atomicAdd(specialRays, (unsigned long long)__popcll(sm));
                 }
                 const uint32_t nIdle = (uint32_t)__popcll(idleMask);
                 rangeLo += nIdle < avail ? nIdle : avail;
@@ -490,8 +486,8 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             if (interiorMask == 0ull || nLeaf >= PT_LEAF_BATCH) break;
             if (refillable && 64u - (uint32_t)__popcll(interiorMask) - nLeaf >= refillMin) break;
             if (STATS) sched[0]++;
-            if (WIDE) {
-                if ((int32_t)cur > 0) {
+            {
+                if ((int32_t)cur > 0 && !special) {
                     if (STATS) (*nsteps)++;
                     const float4* p = sc.quads + 8 * (size_t)(cur - 1u);
                     const float4 mnx = p[0], mny = p[1], mnz = p[2], mxx = p[3], mxy = p[4], mxz = p[5];
@@ -567,22 +563,17 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     if (k0 != PT_KEY_MISS) enter(e0);
                     else popNext();
                 }
-            } else {
-                const bool nanSafe = __any((int32_t)cur > 0 && special);
-                if ((int32_t)cur > 0) {
+            }
+            // the rare lanes whose ray can produce NaN slab distances: the two-wide, NaN-rejecting step over the pair records
+            if (__any((int32_t)cur > 0 && special)) {
+                if ((int32_t)cur > 0 && special) {
                     if (STATS) (*nsteps)++;
                     const int32_t node = (int32_t)cur;
                     const float4* p = sc.pairs + 2 * (size_t)(node - 1);   // pair (node-1)/2, 4 float4 each
                     const float4 a = p[0], b = p[1], c = p[2], e = p[3];
                     float lt, rt;
-                    bool lhit, rhit;
-                    if (nanSafe) {
-                        lhit = slabTest<true>(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, &lt);
-                        rhit = slabTest<true>(c.x, c.y, c.z, c.w, e.x, e.y, o, inv, &rt);
-                    } else {
-                        lhit = slabTest<false>(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, &lt);
-                        rhit = slabTest<false>(c.x, c.y, c.z, c.w, e.x, e.y, o, inv, &rt);
-                    }
+                    bool lhit = slabTest<true>(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, &lt);
+                    bool rhit = slabTest<true>(c.x, c.y, c.z, c.w, e.x, e.y, o, inv, &rt);
                     if (ANYHIT) { lhit = lhit && lt < tlimit; rhit = rhit && rt < tlimit; }
                     else { lhit = lhit && !(lt > best); rhit = rhit && !(rt > best); }
                     const uint32_t eL = __float_as_uint(b.z), eR = __float_as_uint(e.z);   // entries, formed at upload
@@ -594,7 +585,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     if (lhit || rhit) enter(nearE);
                     else popNext();
                 }
-                    }
+            }
         }
         // ---- triangle tests, one per waiting lane and iteration
         for (;;) {

@@ -51,7 +51,6 @@ struct Queues {
     float4* sd;        // shadow direction.xyz, birth (bits)
     float4* sc;        // shadow contribution rgba
     float4* plane;     // per-path radiance of the batch, indexed by birth
-    uint32_t* special; // indices of the rays of the running stage that take the two-wide traversal
 };
 
 // ------------------------------------------------------------------ generate
@@ -114,32 +113,17 @@ struct ExtendSource {
     }
 };
 
-// Rays `list[0..n)` of another source: the two-wide pass over the rays the wide pass set aside.
-template <class Source>
-struct ListSource {
-    Source inner;
-    const uint32_t* list;
-    __device__ __forceinline__ void load(uint32_t i, f3* ro, f3* rd, float* tlimit) const { inner.load(list[i], ro, rd, tlimit); }
-    __device__ __forceinline__ void store(uint32_t i, const HitRec& h, bool occluded) const { inner.store(list[i], h, occluded); }
-};
-
-// SPECIAL = false: the wide traversal of every ray of the queue; rays it cannot take are listed in q.special.
-// SPECIAL = true: the two-wide traversal of the listed rays (launched right after, usually with nothing to do).
-template <bool STATS, bool SPECIAL>
+template <bool STATS>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
     unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
-    const uint32_t n = SPECIAL ? ctl->special_extend : ctl->count[cur];
-    if (SPECIAL && n == 0u) return;
-    if (SPECIAL && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->special_rays, (unsigned long long)n);
-    if (!SPECIAL && blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t n = ctl->count[cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         // counters of the stages that follow this launch
         ctl->count[cur ^ 1] = 0;
         ctl->shadow_count = 0;
-        ctl->special_connect = 0;
-        ctl->cursor_special = 0;
         atomicAdd(&ctl->extend_rays, (unsigned long long)n);
     }
     uint32_t steps = 0, tris = 0, overflow = 0;
@@ -148,14 +132,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene
     src.d = q.d[cur];
     src.hit = q.hit;
     uint32_t sched[3] = {0, 0, 0};
-    if (SPECIAL) {
-        ListSource<ExtendSource> ls;
-        ls.inner = src;
-        ls.list = q.special;
-        traverseWave<false, STATS, false>(sc, n, &ctl->cursor_special, lstack, leafq, ls, &steps, &tris, &overflow, sched, refillMin);
-    } else {
-        traverseWave<false, STATS, true>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_extend, q.special);
-    }
+    traverseWave<false, STATS>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
     if (STATS) {
         waveAdd64(&ctl->extend_steps, steps);
         waveAdd64(&ctl->extend_tris, tris);
@@ -190,16 +167,14 @@ struct ConnectSource {
     }
 };
 
-template <bool STATS, bool SPECIAL>
+template <bool STATS>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScene sc, Queues q, Ctl* ctl, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
     unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
-    const uint32_t n = SPECIAL ? ctl->special_connect : ctl->shadow_count;
-    if (SPECIAL && n == 0u) return;
-    if (SPECIAL && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->special_rays, (unsigned long long)n);
-    if (!SPECIAL && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->shadow_rays, (unsigned long long)n);
+    const uint32_t n = ctl->shadow_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->shadow_rays, (unsigned long long)n);
     uint32_t steps = 0, tris = 0, overflow = 0;
     ConnectSource src;
     src.so = q.so;
@@ -207,14 +182,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScen
     src.sc = q.sc;
     src.plane = q.plane;
     uint32_t sched[3] = {0, 0, 0};
-    if (SPECIAL) {
-        ListSource<ConnectSource> ls;
-        ls.inner = src;
-        ls.list = q.special;
-        traverseWave<true, STATS, false>(sc, n, &ctl->cursor_special, lstack, leafq, ls, &steps, &tris, &overflow, sched, refillMin);
-    } else {
-        traverseWave<true, STATS, true>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_connect, q.special);
-    }
+    traverseWave<true, STATS>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
     if (STATS) {
         waveAdd64(&ctl->shadow_steps, steps);
         waveAdd64(&ctl->shadow_tris, tris);
@@ -353,8 +321,6 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DevSce
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl->cursor_extend = 0;
         ctl->cursor_connect = 0;
-        ctl->cursor_special = 0;
-        ctl->special_extend = 0;
     }
     const uint32_t stride = gridDim.x * blockDim.x;
     // every lane of a wave runs the same number of iterations: the compaction below is wave-wide
@@ -569,25 +535,17 @@ struct TraceSource {
     }
 };
 
-// One wave per 64 rays (grid sized by the caller), no shared cursor.  SPECIAL as for k_extend, with the
-// list in `special` and its length in ctl->special_extend.
-template <bool ANYHIT, bool SPECIAL>
-__global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src, int n, Ctl* ctl, uint32_t* special) {
-    const uint32_t refillMin = PT_REFILL_MIN;   // no shared cursor here: every wave traces its own 64 rays and never refills
+// One wave per 64 rays (grid sized by the caller), no shared cursor.
+template <bool ANYHIT>
+__global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src, int n, Ctl* ctl) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
     unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
     uint32_t steps = 0, tris = 0, overflow = 0;
     uint32_t sched[3] = {0, 0, 0};
-    if (SPECIAL) {
-        ListSource<TraceSource> ls;
-        ls.inner = src;
-        ls.list = special;
-        traverseWave<ANYHIT, false, false>(sc, ctl->special_extend, nullptr, lstack, leafq, ls, &steps, &tris, &overflow, sched, refillMin);
-    } else {
-        traverseWave<ANYHIT, false, true>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_extend, special);
-    }
+    // every wave traces its own 64 rays and never refills: the threshold is not used
+    traverseWave<ANYHIT, false>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, 64u, &ctl->special_rays);
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
 }
 
@@ -597,8 +555,5 @@ __global__ void k_set_ctl(Ctl* ctl, uint32_t count0, unsigned long long paths) {
     ctl->shadow_count = 0;
     ctl->cursor_extend = 0;
     ctl->cursor_connect = 0;
-    ctl->cursor_special = 0;
-    ctl->special_extend = 0;
-    ctl->special_connect = 0;
     ctl->paths += paths;
 }

@@ -124,8 +124,8 @@ def test_axis_aligned_and_degenerate_rays(ob, bundled, wf_bundled):
 
 
 def test_special_rays_in_the_extend_stage(ob, bundled, wf_bundled):
-    """The wide traversal sets rays with NaN-capable slab distances aside for the two-wide pass: a queue that mixes
-    both kinds must come out exactly as the per-ray queries do."""
+    """Rays with NaN-capable slab distances take the two-wide step inside the wide kernel: a queue that mixes both kinds
+    (both kinds in one wave) must come out exactly as the per-ray queries do."""
     rng = np.random.default_rng(5)
     n = 4096
     rays = np.zeros((n, 6), np.float32)
@@ -229,7 +229,7 @@ def test_device_built_scene_renders_identically(pa, ob, bundled, wf_bundled):
     rays[:, 0:3] = rng.uniform(-8, 8, (n, 3)).astype(np.float32) + np.array([0, 9, 0], np.float32)
     d = rng.normal(size=(n, 3)).astype(np.float32)
     rays[:, 3:6] = d / np.sqrt((d * d).sum(1, dtype=np.float32))[:, None]
-    rays[::7, 4] = 0.0                      # some rays for the two-wide pass (pair records)
+    rays[::7, 4] = 0.0                      # some rays for the two-wide walk (pair records)
     a, b = wf.trace_closest(rays), wf_bundled.trace_closest(rays)
     for k in ("tri", "t", "uv"):
         assert np.array_equal(bits(a[k]), bits(b[k])), k
