@@ -21,7 +21,7 @@ def main():
     out, prof = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
     vals = {}
     for line in open(os.path.join(out, "final_pmc_summary.txt")):
-        m = re.match(r"void k_extend<false, false>\s+(\S+)\s+mean/dispatch\s+([\d.]+)", line)
+        m = re.match(r"void k_extend<false>\s+(\S+)\s+mean/dispatch\s+([\d.]+)", line)
         if m:
             vals[m.group(1)] = float(m.group(2))
     rd = 128 * vals["TCC_EA0_RDREQ_128B_sum"] + 64 * vals["TCC_EA0_RDREQ_64B_sum"] + 32 * vals["TCC_EA0_RDREQ_32B_sum"]
