@@ -380,6 +380,11 @@ def test_context_lifecycle(pa, bundled, cornell):
     assert e.value.code == -6
     with pytest.raises(pa.PtError):
         wf.allocate(0, 48)
+    for key, bad in ((1, 3), (2, 2), (4, 3), (6, 17), (7, 0), (7, 65), (8, 0), (99, 1)):
+        with pytest.raises(pa.PtError):
+            wf.set_option(key, bad)
+    wf.set_option(7, 16)                                        # scheduling knobs cannot change the image
+    wf.set_option(8, 64)
     wf.allocate(64, 48)
     with pytest.raises(pa.PtError):
         wf.invoke(fs, spp=0, max_bounces=4)
