@@ -109,7 +109,11 @@ uint32_t chooseBatch(const pt_ctx* c, uint32_t spp) {
     }
     // queue indices are 32-bit: never more than 2^30 paths in flight
     const uint32_t cap = std::max(1u, (1u << 30) / std::max(1u, c->slots));
-    return std::max(1u, std::min(std::min(want, cap), std::max(1u, spp)));
+    const uint32_t most = std::max(1u, std::min(std::min(want, cap), std::max(1u, spp)));
+    if (c->cfg.samples_per_batch != 0) return most;   // an explicit size is taken literally
+    // equal batches: 128 samples at 123 per batch would leave a second batch of 5 that cannot fill the chip
+    const uint32_t batches = (std::max(1u, spp) + most - 1u) / most;
+    return (std::max(1u, spp) + batches - 1u) / batches;
 }
 
 hipEvent_t getEvent(pt_ctx* c) {
