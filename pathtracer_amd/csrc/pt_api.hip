@@ -196,6 +196,26 @@ void appendLight(const HostTriangle& t, std::vector<float4>& lights, float& ligh
 
 }  // namespace
 
+namespace {
+// Nothing may unwind through the C boundary: host allocations of an entry point (std::vector, new) that fail become PT_E_OOM.
+template <class F>
+int guarded(pt_ctx* c, const char* what, F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        char b[128];
+        snprintf(b, sizeof(b), "%s: out of host memory", what);
+        if (c) c->err = b; else g_err = b;
+        return PT_E_OOM;
+    } catch (const std::exception& e) {
+        char b[256];
+        snprintf(b, sizeof(b), "%s: %s", what, e.what());
+        if (c) c->err = b; else g_err = b;
+        return PT_E_HIP;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int pt_default_config(pt_config* cfg) {
@@ -208,7 +228,7 @@ int pt_default_config(pt_config* cfg) {
 
 const char* pt_last_error(pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
-int pt_create(const pt_config* cfg, pt_ctx** out) {
+static int impl_create(const pt_config* cfg, pt_ctx** out) {
     if (!cfg || !out) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: null argument");
     if (cfg->struct_size != (int32_t)sizeof(pt_config)) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: struct_size %d, expected %zu", cfg->struct_size, sizeof(pt_config));
     if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: tile rank %d of %d", cfg->tile_rank, cfg->tile_world);
@@ -283,7 +303,7 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
     return PT_OK;
 }
 
-int pt_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles, int32_t n_tri, const void* nodes, int32_t n_nodes) {
+static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles, int32_t n_tri, const void* nodes, int32_t n_nodes) {
     if (!c) return PT_E_INVALID_ARG;
     if (n_mat < 0 || n_tri < 0 || n_nodes < 0 || (n_mat && !materials) || (n_tri && !triangles) || (n_nodes && !nodes)) FAIL(c, PT_E_INVALID_ARG, "pt_upload_scene: bad counts or null arrays");
     HIPCHECK(c, hipSetDevice(c->cfg.device));
@@ -402,7 +422,7 @@ int pt_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void*
     return PT_OK;
 }
 
-int pt_resize(pt_ctx* c, int32_t width, int32_t height) {
+static int impl_resize(pt_ctx* c, int32_t width, int32_t height) {
     if (!c) return PT_E_INVALID_ARG;
     if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28)) FAIL(c, PT_E_INVALID_ARG, "pt_resize: %d x %d", width, height);
     HIPCHECK(c, hipSetDevice(c->cfg.device));
@@ -523,7 +543,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
     return PT_OK;
 }
 
-int pt_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32_t max_bounces) {
+static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32_t max_bounces) {
     if (!c || !frame_state112) return PT_E_INVALID_ARG;
     if (spp < 1 || max_bounces < 1 || max_bounces > 64) FAIL(c, PT_E_INVALID_ARG, "pt_render: spp %d, max_bounces %d", spp, max_bounces);
     if (!c->has_scene) FAIL(c, PT_E_STATE, "pt_render before pt_upload_scene");
@@ -569,7 +589,7 @@ int pt_accum_device(pt_ctx* c, void** device_ptr, uint64_t* n_slots_padded, uint
     return PT_OK;
 }
 
-int pt_assemble_tiles(pt_ctx* c, const void* gathered_device, int32_t world, uint32_t samples, float* rgba_host) {
+static int impl_assemble_tiles(pt_ctx* c, const void* gathered_device, int32_t world, uint32_t samples, float* rgba_host) {
     if (!c || !gathered_device || !rgba_host) return PT_E_INVALID_ARG;
     if (world != c->cfg.tile_world) FAIL(c, PT_E_INVALID_ARG, "pt_assemble_tiles: world %d, context was created for %d", world, c->cfg.tile_world);
     if (!c->d_image) FAIL(c, PT_E_STATE, "pt_assemble_tiles before pt_resize");
@@ -581,7 +601,7 @@ int pt_assemble_tiles(pt_ctx* c, const void* gathered_device, int32_t world, uin
     return pt_synchronize(c);
 }
 
-int pt_read_image(pt_ctx* c, float* rgba) {
+static int impl_read_image(pt_ctx* c, float* rgba) {
     if (!c || !rgba) return PT_E_INVALID_ARG;
     if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_read_image before pt_resize");
     if (c->cfg.tile_world != 1) FAIL(c, PT_E_STATE, "pt_read_image on a tile-sharded context: gather with pt_accum_device + pt_assemble_tiles");
@@ -627,16 +647,16 @@ static int traceCommon(pt_ctx* c, bool anyhit, const float* o_d, const float* tm
     return rc;
 }
 
-int pt_trace_closest(pt_ctx* c, const float* o_d, int32_t n, int32_t* tri, float* t, float* uv) {
+static int impl_trace_closest(pt_ctx* c, const float* o_d, int32_t n, int32_t* tri, float* t, float* uv) {
     return traceCommon(c, false, o_d, nullptr, n, tri, t, uv, nullptr);
 }
 
-int pt_trace_occluded(pt_ctx* c, const float* o_d, const float* tmax, int32_t n, uint8_t* occluded) {
+static int impl_trace_occluded(pt_ctx* c, const float* o_d, const float* tmax, int32_t n, uint8_t* occluded) {
     if (n > 0 && (!tmax || !occluded)) return PT_E_INVALID_ARG;
     return traceCommon(c, true, o_d, tmax, n, nullptr, nullptr, nullptr, occluded);
 }
 
-int pt_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, float* o_d, uint32_t* pixel) {
+static int impl_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, float* o_d, uint32_t* pixel) {
     if (!c || !frame_state112 || !o_d || !pixel || n < 0) return PT_E_INVALID_ARG;
     if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_generate_rays before pt_resize");
     if (!c->has_rs) FAIL(c, PT_E_STATE, "pt_generate_rays before pt_set_render_state");
@@ -671,7 +691,7 @@ int pt_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, float* o_
     return PT_OK;
 }
 
-int pt_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t iters, float* avg_ms, int32_t* tri, float* t) {
+static int impl_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t iters, float* avg_ms, int32_t* tri, float* t) {
     if (!c || !o_d || n <= 0 || iters <= 0 || !avg_ms) return PT_E_INVALID_ARG;
     if (!c->has_scene) FAIL(c, PT_E_STATE, "pt_bench_extend before pt_upload_scene");
     HIPCHECK(c, hipSetDevice(c->cfg.device));
@@ -714,7 +734,7 @@ int pt_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t iters, float
     return PT_OK;
 }
 
-int pt_build_bvh(pt_ctx* c, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out, int32_t node_capacity, int32_t* n_nodes,
+static int impl_build_bvh(pt_ctx* c, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out, int32_t node_capacity, int32_t* n_nodes,
                  float* build_ms) {
     if (!c || n_tri < 0 || (n_tri && (!triangles_in || !triangles_out)) || !nodes_out || !n_nodes) return PT_E_INVALID_ARG;
     const int32_t need = n_tri ? 2 * n_tri - 1 : 1;
@@ -750,7 +770,7 @@ int pt_build_bvh(pt_ctx* c, const void* triangles_in, int32_t n_tri, void* trian
     return PT_OK;
 }
 
-int pt_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out,
+static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out,
                    int32_t node_capacity, int32_t* n_nodes, float* build_ms) {
     if (!c || n_mat < 0 || n_tri < 0 || (n_mat && !materials) || (n_tri && !triangles_in)) return PT_E_INVALID_ARG;
     const int32_t need = n_tri ? 2 * n_tri - 1 : 1;
@@ -911,5 +931,19 @@ int pt_reset_stats(pt_ctx* c) {
     c->host_stats = pt_stats{};
     return PT_OK;
 }
+
+// ---- the exported entry points that allocate on the host, each behind the exception barrier
+int pt_create(const pt_config* cfg, pt_ctx** out) { return guarded((pt_ctx*)nullptr, "pt_create", [&]() -> int { return impl_create(cfg, out); }); }
+int pt_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles, int32_t n_tri, const void* nodes, int32_t n_nodes) { return guarded(c, "pt_upload_scene", [&]() -> int { return impl_upload_scene(c, materials, n_mat, triangles, n_tri, nodes, n_nodes); }); }
+int pt_resize(pt_ctx* c, int32_t width, int32_t height) { return guarded(c, "pt_resize", [&]() -> int { return impl_resize(c, width, height); }); }
+int pt_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32_t max_bounces) { return guarded(c, "pt_render", [&]() -> int { return impl_render(c, frame_state112, spp, max_bounces); }); }
+int pt_read_image(pt_ctx* c, float* rgba) { return guarded(c, "pt_read_image", [&]() -> int { return impl_read_image(c, rgba); }); }
+int pt_assemble_tiles(pt_ctx* c, const void* gathered_device, int32_t world, uint32_t samples, float* rgba_host) { return guarded(c, "pt_assemble_tiles", [&]() -> int { return impl_assemble_tiles(c, gathered_device, world, samples, rgba_host); }); }
+int pt_trace_closest(pt_ctx* c, const float* o_d, int32_t n, int32_t* tri, float* t, float* uv) { return guarded(c, "pt_trace_closest", [&]() -> int { return impl_trace_closest(c, o_d, n, tri, t, uv); }); }
+int pt_trace_occluded(pt_ctx* c, const float* o_d, const float* tmax, int32_t n, uint8_t* occluded) { return guarded(c, "pt_trace_occluded", [&]() -> int { return impl_trace_occluded(c, o_d, tmax, n, occluded); }); }
+int pt_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, float* o_d, uint32_t* pixel) { return guarded(c, "pt_generate_rays", [&]() -> int { return impl_generate_rays(c, frame_state112, n, o_d, pixel); }); }
+int pt_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t iters, float* avg_ms, int32_t* tri, float* t) { return guarded(c, "pt_bench_extend", [&]() -> int { return impl_bench_extend(c, o_d, n, iters, avg_ms, tri, t); }); }
+int pt_build_bvh(pt_ctx* c, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out, int32_t node_capacity, int32_t* n_nodes, float* build_ms) { return guarded(c, "pt_build_bvh", [&]() -> int { return impl_build_bvh(c, triangles_in, n_tri, triangles_out, nodes_out, node_capacity, n_nodes, build_ms); }); }
+int pt_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out, int32_t node_capacity, int32_t* n_nodes, float* build_ms) { return guarded(c, "pt_build_scene", [&]() -> int { return impl_build_scene(c, materials, n_mat, triangles_in, n_tri, triangles_out, nodes_out, node_capacity, n_nodes, build_ms); }); }
 
 }  // extern "C"
