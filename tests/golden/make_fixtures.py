@@ -4,6 +4,7 @@
   pathtracer_amd/assets/meshes.bin   parsed arrays of the reference's OBJ/MTL assets (needs /root/reference)
   tests/golden/oracle_golden.json    digests of the oracle's bundled scene and primary hits
   tests/golden/oracle_golden.npz     a 64x64 crop of the 512x512 hit-id image and a 64x64 radiance sum
+  tests/golden/oracle_golden_mis.npz a 32x32 radiance sum of the Cornell box with NEE + multiple importance sampling
 
 The reference has no golden vectors of its own; these freeze the CPU oracle's outputs (which were
 checked against the .NET System.Random known answers, brute-force traversal and BVH invariants in
@@ -50,6 +51,13 @@ def main():
     fs64, _ = s.camera((0, 2, 15), (0, 3, 0), 64, 64, use_scene=False, frames=1, samples=1)
     img, _ = s.render(ob.render_state(64, 64), fs64, ob.path_config(4, 1, 0), 4, threads=8)
     np.savez_compressed(os.path.join(HERE, "oracle_golden.npz"), hit_ids_crop=lit["tri"].reshape(h, w)[224:288, 224:288], radiance_64_sum=img)
+    # Cornell box with next-event estimation and multiple importance sampling (the estimator that is not in the reference)
+    c = ob.Scene(MESHES)
+    c.add_mesh("cornell")
+    c.build()
+    fsc, _ = c.camera((0, 1, 3.4), (0, 1, 0), 32, 32, use_scene=True, frames=1, samples=1)
+    imgc, _ = c.render(ob.render_state(32, 32, sky=(0, 0, 0, 1)), fsc, ob.path_config(5, 2, 1), 8, threads=8)
+    np.savez_compressed(os.path.join(HERE, "oracle_golden_mis.npz"), cornell_mis_32_sum=imgc)
     print(json.dumps(g, indent=1))
 
 

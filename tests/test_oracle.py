@@ -247,3 +247,12 @@ def test_golden_fixtures(ob, bundled):
     assert np.array_equal(lit["tri"].reshape(h, w)[224:288, 224:288], z["hit_ids_crop"])
     img, _ = bundled.render(ob.render_state(64, 64), bundled_view(bundled, 64, 64, frames=1), ob.path_config(4, 1, 0), 4, threads=8)
     assert np.array_equal(bits(img), bits(z["radiance_64_sum"]))
+
+
+def test_golden_fixture_mis(ob, cornell):
+    """Frozen oracle output of the estimator with multiple importance sampling (Cornell box, 32x32, 8 spp)."""
+    z = np.load(os.path.join(GOLDEN, "oracle_golden_mis.npz"))
+    fs, _ = cornell.camera((0, 1, 3.4), (0, 1, 0), 32, 32, use_scene=True, frames=1, samples=1)
+    img, _ = cornell.render(ob.render_state(32, 32, sky=(0, 0, 0, 1)), fs, ob.path_config(5, 2, 1), 8, threads=8)
+    assert np.isfinite(img).all() and img[..., :3].mean() > 0.05
+    assert np.array_equal(bits(img), bits(z["cornell_mis_32_sum"]))
