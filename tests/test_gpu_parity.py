@@ -257,6 +257,51 @@ def test_device_built_scene_renders_identically(pa, ob, bundled, wf_bundled):
     ref.close()
 
 
+def test_against_committed_golden_fixtures(pa):
+    """The product alone (host mirror + HIP path, no oracle in the process of this test) against tests/golden/: scene
+    digests, the 512x512 primary hit image of the literal C# traversal, and two frozen radiance sums (bundled scene with
+    NEE; Cornell box with multiple importance sampling)."""
+    import hashlib
+    import json
+    from pathtracer_amd.host import Scene, Camera
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = json.load(open(os.path.join(golden, "oracle_golden.json")))["bundled"]
+    z = np.load(os.path.join(golden, "oracle_golden.npz"))
+    zm = np.load(os.path.join(golden, "oracle_golden_mis.npz"))
+    s = Scene()
+    s.initialize_scene(11)
+    s.build()
+    mats, tris, nodes = s.arrays()
+    assert hashlib.sha256(mats.tobytes()).hexdigest() == g["materials_sha256"]
+    assert hashlib.sha256(tris.tobytes()).hexdigest() == g["triangles_sha256"]
+    assert hashlib.sha256(nodes.tobytes()).hexdigest() == g["nodes_sha256"]
+    wf = pa.Wavefront(nee=True, rng_mode=0)
+    wf.upload_scene(mats, tris, nodes)
+    w = h = 512
+    wf.allocate(w, h)
+    fs = Camera(w, h).frame_state((0, 2, 15), (0, 3, 0), frames=1, samples=1)
+    rays, _ = wf.generate_rays(fs, w * h)
+    hit = wf.trace_closest(rays)
+    assert hashlib.sha256(hit["tri"].tobytes()).hexdigest() == g["primary_512_hit_ids_sha256"]
+    assert hashlib.sha256(hit["t"].tobytes()).hexdigest() == g["primary_512_hit_t_sha256"]
+    assert np.array_equal(hit["tri"].reshape(h, w)[224:288, 224:288], z["hit_ids_crop"])
+    wf.allocate(64, 64)
+    wf.invoke(Camera(64, 64).frame_state((0, 2, 15), (0, 3, 0), frames=1, samples=1), spp=4, max_bounces=4)
+    assert np.array_equal(bits(wf.read_image() * np.float32(4)), bits(z["radiance_64_sum"]))
+    wf.close()
+
+    c = Scene()
+    c.add_mesh("cornell")
+    c.build()
+    wf = pa.Wavefront(nee=2, rng_mode=1)
+    wf.upload_scene(*c.arrays())
+    wf.allocate(32, 32, sky=(0, 0, 0, 1))
+    fs = Camera(32, 32, wf).frame_state((0, 1, 3.4), (0, 1, 0), frames=1, samples=1)
+    wf.invoke(fs, spp=8, max_bounces=5)
+    assert np.array_equal(bits(wf.read_image() * np.float32(8)), bits(zm["cornell_mis_32_sum"]))
+    wf.close()
+
+
 def test_tiny_and_empty_scenes(pa, ob):
     # 2 triangles: the root stays a leaf (Count < 3, Accelerator.cs:138)
     s = ob.Scene(pa_assets())
