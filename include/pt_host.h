@@ -72,6 +72,11 @@ int pth_scene_counts(pth_scene* s, int32_t* out4);
 /* The CPU mirrors of Buffer<Material>, Buffer<Triangle>, Buffer<Node> (valid until the scene changes). */
 int pth_scene_arrays(pth_scene* s, const void** materials48, const void** triangles112, const void** nodes32);
 
+/* The triangles as Accelerator.AddTriangle collected them (PathTracer/Accelerator.cs:38-49: insertion order, before any
+ * build) and the materials: the input of pt_build_bvh / pt_build_scene when the tree is to be built on the GPU.
+ * Valid until the scene changes. */
+int pth_scene_references(pth_scene* s, const void** triangles112, const void** materials48, int32_t* n_triangles, int32_t* n_materials);
+
 /* Camera.Update, PathTracer/Camera.cs:46-61, in two halves around the autofocus ray of
  * Camera.GetFocalDistance (Camera.cs:89-95), which the caller traces with pt_trace_closest:
  * pth_camera_basis gives forward/right/up; pth_camera_state takes the hit distance of the ray

@@ -26,6 +26,7 @@ public:
     void Build(int threads = 1);                  // Accelerator.cs:113-134
     void Clear();                                 // Accelerator.cs:179-186
     int Count() const { return (int)references.size(); }
+    const std::vector<Triangle>& References() const { return references; }   // the triangles in AddTriangle order
     int Depth() const;
 
     std::vector<Triangle> triangles;              // Buffer<Triangle> mirror, valid after Build

@@ -695,6 +695,12 @@ int pth_scene_arrays(pth_scene* s, const void** materials48, const void** triang
               if (nodes32) *nodes32 = s->accelerator.nodes.data())
 }
 
+int pth_scene_references(pth_scene* s, const void** triangles112, const void** materials48, int32_t* n_triangles, int32_t* n_materials) {
+    PTH_GUARD(const std::vector<Triangle>& r = s->accelerator.References();
+              if (triangles112) *triangles112 = r.data(); if (materials48) *materials48 = s->materials.data();
+              if (n_triangles) *n_triangles = (int32_t)r.size(); if (n_materials) *n_materials = (int32_t)s->materials.size())
+}
+
 // Camera.Update first half, Camera.cs:48-50
 int pth_camera_basis(const float* position3, const float* target3, float* forward3, float* right3, float* up3) {
     PTH_GUARD(

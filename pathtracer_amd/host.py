@@ -42,6 +42,7 @@ def _lib():
         lib.pth_scene_save.argtypes = [vp, C.c_char_p]
         lib.pth_scene_load.argtypes = [vp, C.c_char_p]
         lib.pth_scene_counts.argtypes = [vp, vp]
+        lib.pth_scene_references.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
         lib.pth_scene_arrays.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         lib.pth_camera_basis.argtypes = [vp, vp, vp, vp, vp]
         lib.pth_camera_state.argtypes = [vp, vp, vp, vp, C.c_float, i32, i32, vp, C.POINTER(C.c_float)]
@@ -135,6 +136,17 @@ class Scene:
         out = np.zeros(4, np.int32)
         _chk(self._lib.pth_scene_counts(self._h, _p(out)))
         return dict(zip(["materials", "triangles", "nodes", "depth"], out.tolist()))
+
+    def references(self):
+        """Copies of (Material[], Triangle[]) in insertion order, before any build: the input of Wavefront.build_scene."""
+        pt, pm, nt, nm = C.c_void_p(), C.c_void_p(), C.c_int32(), C.c_int32()
+        _chk(self._lib.pth_scene_references(self._h, C.byref(pt), C.byref(pm), C.byref(nt), C.byref(nm)))
+
+        def view(ptr, n, dt):
+            if n == 0:
+                return np.zeros(0, dt)
+            return np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(ptr.value), dtype=dt, count=n).copy()
+        return view(pm, nm.value, MATERIAL), view(pt, nt.value, TRIANGLE)
 
     def arrays(self):
         """Copies of (Material[], Triangle[], Node[]) — what Scene.CopyToDevice uploads."""

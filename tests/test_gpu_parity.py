@@ -642,6 +642,47 @@ def test_plain_c_host_renders_the_same_image(pa, bundled, tmp_path):
             assert np.isfinite(got).all() and abs(float(got[..., :3].mean()) / float(want[..., :3].mean()) - 1.0) < 0.03, r.stdout
 
 
+def test_command_line_renderer(pa, bundled, tmp_path):
+    """python -m pathtracer_amd: the float image it writes equals a render through the API; the GPU-built variant (another
+    valid tree over the same triangles) gives the same picture up to its light order; the PNG is well formed."""
+    import struct
+    import subprocess
+    import sys
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [sys.executable, "-m", "pathtracer_amd", "--width", "160", "--height", "96", "--spp", "4", "--bounces", "4", "--nee", "1"]
+
+    def run(extra):
+        r = subprocess.run(common + extra, cwd=root, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "165208 triangles" in r.stdout
+        return r.stdout
+
+    def read_pfm(path):
+        b = open(path, "rb").read()
+        head = b"PF\n160 96\n-1.0\n"
+        assert b.startswith(head)
+        return np.frombuffer(b[len(head):], np.float32).reshape(96, 160, 3)
+
+    run(["--out", str(tmp_path / "a.pfm")])
+    run(["--out", str(tmp_path / "b.pfm"), "--gpu-build"])
+    run(["--out", str(tmp_path / "a.png")])
+    wf = make_wf(pa, bundled, nee=1, rng_mode=1)
+    wf.allocate(160, 96)
+    wf.invoke(bundled_view(bundled, 160, 96, frames=1), spp=4, max_bounces=4)
+    ref = wf.read_image()[..., :3]
+    wf.close()
+    a, b = read_pfm(tmp_path / "a.pfm"), read_pfm(tmp_path / "b.pfm")
+    assert np.array_equal(bits(a), bits(ref))
+    assert np.isfinite(b).all() and abs(float(b.mean()) - float(a.mean())) <= 0.03 * float(a.mean())
+    png = open(tmp_path / "a.png", "rb").read()
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    w_, h_ = struct.unpack(">II", png[16:24])
+    assert (w_, h_) == (160, 96)
+    idat = png[png.index(b"IDAT") + 4:png.index(b"IEND") - 8]
+    assert len(zlib.decompress(idat)) == 96 * (160 * 3 + 1)
+
+
 def test_tile_sharding_single_process(pa, ob, bundled):
     """world=3 contexts on one GPU: assembling their accumulators gives the 1-GPU image bit for bit."""
     import torch

@@ -135,6 +135,22 @@ def test_scene_cache_file_round_trip(host, tmp_path):
         t.load(str(tmp_path / "missing.bin"))
 
 
+def test_references_are_the_insertion_order(host):
+    """Scene.references: the triangles as AddTriangle collected them, available before any build and unchanged by it;
+    the built array is a permutation of them."""
+    s = host.Scene()
+    s.add_mesh("cube")
+    s.add_mesh("light")
+    mats, refs = s.references()
+    assert refs.size == 14 and mats.size >= 2
+    s.build()
+    mats2, refs2 = s.references()
+    assert refs2.tobytes() == refs.tobytes() and mats2.tobytes() == mats.tobytes()
+    _, tris, _ = s.arrays()
+    key = lambda a: sorted(a[i].tobytes() for i in range(a.size))
+    assert key(tris) == key(refs)
+
+
 def test_image_writers(host, tmp_path):
     """PFM is lossless; PPM and PNG hold what the reference's window would show (clamp, 8 bits, row 0 at the bottom,
     Shaders/Quad/fragment.glsl:9-10) or the sRGB-encoded exposure; the PNG is a valid file (CRC, zlib, Adler)."""
