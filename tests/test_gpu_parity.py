@@ -326,6 +326,52 @@ def test_tiny_and_empty_scenes(pa, ob):
     wf.close()
 
 
+def test_random_scenes_of_many_sizes(pa, ob):
+    """Ragged inputs: random triangle sets of 1 .. 4099 triangles, with zero-area, duplicated and far-away triangles
+    mixed in.  For every size the GPU-built tree equals the oracle's literal build byte for byte, and closest / any hits
+    of rays aimed through the set (some axis-aligned, some starting on a triangle) equal the oracle's bit for bit."""
+    rng = np.random.default_rng(77)
+    mats = np.zeros(1, pa.MATERIAL)
+    mats["color"] = 0.7
+    wf = pa.Wavefront()
+    for n in (1, 2, 3, 5, 17, 64, 257, 1000, 4099):
+        tris = np.zeros(n, pa.TRIANGLE)
+        c = rng.uniform(-4, 4, (n, 1, 3)).astype(np.float32)
+        v = c + rng.uniform(-0.8, 0.8, (n, 3, 3)).astype(np.float32)
+        if n >= 5:
+            v[1] = v[0]                                   # a duplicate
+            v[2, 1] = v[2, 0]                             # zero area: two equal vertices
+            v[3, :, :] = v[3, 0:1, :]                     # a point
+            v[4] += np.float32(300.0)                     # an outlier that stretches the root box
+        for k, name in enumerate(("v1", "v2", "v3")):
+            tris[name]["position"] = v[:, k, :]
+            tris[name]["normal"] = (0, 1, 0)
+        s = ob.Scene("")
+        s.set_materials(mats)
+        s.add_triangles(tris)
+        s.build()
+        omats, otris, onodes, refs = s.arrays(references=True)
+        gt, gn, _ = wf.build_bvh(refs)
+        assert gt.tobytes() == otris.tobytes() and gn.tobytes() == onodes.tobytes(), n
+        wf.upload_scene(omats, otris, onodes)
+        m = 2048
+        o = rng.uniform(-6, 6, (m, 3)).astype(np.float32)
+        d = (rng.uniform(-4, 4, (m, 3)).astype(np.float32) - o)
+        d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+        d[::16] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, len(d[::16]))]          # axis-aligned (zero components)
+        o[1::16] = v[rng.integers(0, n, len(o[1::16])), 0, :]                             # starting on a vertex
+        rays = np.concatenate([o, d], 1)
+        g = wf.trace_closest(rays)
+        can = s.intersect(rays, "canonical")
+        assert np.array_equal(g["tri"], can["tri"]) and np.array_equal(bits(g["t"]), bits(can["t"])), n
+        lit = s.intersect(rays, "literal")
+        assert np.array_equal(bits(g["t"]), bits(lit["t"])), n       # ids may differ from the literal order only on exact ties
+        tmax = rng.uniform(0.5, 12, m).astype(np.float32)
+        assert np.array_equal(wf.trace_occluded(rays, tmax), s.occluded(rays, tmax)), n
+    assert wf.stats()["stack_overflows"] == 0
+    wf.close()
+
+
 def test_big_leaves(pa, ob):
     """Coincident triangles cannot be split by SAH: leaves of 40 and 17 triangles (beyond the 15 a packed
     stack entry holds) next to ordinary ones; ties among the copies go to the smallest index."""
