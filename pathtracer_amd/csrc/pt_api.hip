@@ -60,6 +60,7 @@ struct pt_ctx {
     // idle lanes a traversal wave collects before it fetches new rays: camera rays of a tile finish together, so waiting for
     // most of the wave costs little and saves refills; scattered rays finish at very different times
     int refill_primary = 48, refill_bounce = 32;
+    uint64_t local_pixels = 0;
     int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
 };
 
@@ -435,6 +436,13 @@ static int impl_resize(pt_ctx* c, int32_t width, int32_t height) {
     c->local_groups = (c->groups + world - 1 - rank) / world;
     c->slots = c->local_groups * 64u;
     c->slots_padded = ((c->groups + world - 1) / world) * 64u;   // the same on every rank
+    // pixels inside the image among this rank's groups (edge groups of a ragged image are partly empty)
+    c->local_pixels = 0;
+    const uint32_t gw = (uint32_t)((width + 7) / 8);
+    for (uint32_t g = rank; g < c->groups; g += world) {
+        const uint32_t gx = g % gw, gy = g / gw;
+        c->local_pixels += (uint64_t)std::min(8u, (uint32_t)width - gx * 8u) * std::min(8u, (uint32_t)height - gy * 8u);
+    }
     HIPCHECK(c, hipMalloc((void**)&c->d_sum, (size_t)std::max(1u, c->slots_padded) * sizeof(float4)));
     HIPCHECK(c, hipMalloc((void**)&c->d_image, (size_t)width * height * sizeof(float4)));
     HIPCHECK(c, hipMemset(c->d_sum, 0, (size_t)std::max(1u, c->slots_padded) * sizeof(float4)));
@@ -537,7 +545,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             cur ^= 1;
         }
         hipLaunchKernelGGL(k_resolve, dim3(launchGrid(c->slots)), dim3(PT_BLOCK), 0, c->stream, c->d_sum, (const float4*)c->q.plane, c->slots, ns);
-        hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, (unsigned long long)total);
+        hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, (unsigned long long)c->local_pixels * ns);
     }
     HIPCHECK(c, hipGetLastError());
     return PT_OK;

@@ -527,6 +527,27 @@ def test_radiance_bundled_256(pa, ob, bundled, wf_bundled, nee, rng_mode, bounce
     wf.set_option(2, 0)
 
 
+@pytest.mark.parametrize("w,h", [(100, 52), (13, 7), (8, 9)])
+def test_radiance_ragged_image_sizes(pa, ob, bundled, wf_bundled, w, h):
+    """Sides that are not multiples of the 8x8 pixel groups (the reference mis-handles them, generate.glsl:177-190; here
+    the edge groups are partly empty): rays are compacted at generation, and the image still equals the oracle's."""
+    wf = wf_bundled
+    wf.set_option(1, 2)
+    wf.set_option(2, 1)
+    wf.allocate(w, h)
+    fs = bundled_view(bundled, w, h, frames=2)
+    wf.reset_stats()
+    wf.invoke(fs, spp=3, max_bounces=4)
+    img = wf.read_image()
+    st = wf.stats()
+    osum, ost = bundled.render(ob.render_state(w, h), fs, ob.path_config(4, 2, 1), 3, threads=8)
+    assert st["extend_rays"] == ost["extend_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert st["paths"] == 3 * w * h
+    assert np.array_equal(bits(img), bits(osum / np.float32(3)))
+    wf.set_option(1, 0)
+    wf.set_option(2, 0)
+
+
 @pytest.mark.parametrize("nee", [1, 2])
 def test_radiance_cornell_nee(pa, ob, cornell, nee):
     """Cornell box (quads, negative indices, no normals -> flat-normal fallback), NEE on, without and with multiple
