@@ -750,10 +750,11 @@ def test_command_line_renderer(pa, bundled, tmp_path):
     assert len(zlib.decompress(idat)) == 96 * (160 * 3 + 1)
 
 
-def test_tile_sharding_single_process(pa, ob, bundled):
+@pytest.mark.parametrize("w,h", [(88, 56), (75, 41)])   # 11 x 7 = 77 groups: not divisible by 3; 10 x 6 groups with ragged edges
+def test_tile_sharding_single_process(pa, ob, bundled, w, h):
     """world=3 contexts on one GPU: assembling their accumulators gives the 1-GPU image bit for bit."""
     import torch
-    w, h, spp = 88, 56, 2     # 11 x 7 = 77 groups: not divisible by 3
+    spp = 2
     fs = bundled_view(bundled, w, h, frames=1)
     ref = make_wf(pa, bundled, nee=True)
     ref.allocate(w, h)
