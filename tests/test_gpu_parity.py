@@ -373,10 +373,12 @@ def test_random_scenes_of_many_sizes(pa, ob):
 
 
 def test_big_leaves(pa, ob):
-    """Coincident triangles cannot be split by SAH: leaves of 40 and 17 triangles (beyond the 15 a packed
-    stack entry holds) next to ordinary ones; ties among the copies go to the smallest index."""
+    """Coincident triangles cannot be split by SAH: leaves of 150 and 17 triangles (beyond the 15 a packed
+    stack entry holds, and the larger one beyond the 64 triangles one leaf phase deals) next to ordinary ones; ties among
+    the copies go to the smallest index."""
     rng = np.random.RandomState(3)
-    tris = np.zeros(40 + 17 + 200, ob.TRIANGLE)
+    big_n = 150
+    tris = np.zeros(big_n + 17 + 200, ob.TRIANGLE)
 
     def put(k, a, b, c):
         n = np.cross(b - a, c - a)
@@ -385,11 +387,11 @@ def test_big_leaves(pa, ob):
             tris[name]["position"][k] = p
             tris[name]["normal"][k] = n
     base = np.array([[0, 0, 0], [2, 0, 0], [0, 2, 0]], np.float32)
-    for k in range(40):
+    for k in range(big_n):
         put(k, *base)
-    for k in range(40, 57):
+    for k in range(big_n, big_n + 17):
         put(k, *(base + np.float32([5, 0, 1])))
-    for k in range(57, tris.size):
+    for k in range(big_n + 17, tris.size):
         c = rng.uniform(-6, 6, 3).astype(np.float32)
         put(k, c, c + rng.uniform(-1, 1, 3).astype(np.float32), c + rng.uniform(-1, 1, 3).astype(np.float32))
     s = ob.Scene("")
@@ -397,7 +399,7 @@ def test_big_leaves(pa, ob):
     s.add_triangles(tris)
     s.build()
     mats, t2, nodes = s.arrays()
-    assert nodes["count"].max() >= 40 and (nodes["count"] == 17).any()
+    assert nodes["count"].max() >= big_n and (nodes["count"] == 17).any()
     wf = pa.Wavefront()
     wf.upload_scene(mats, t2, nodes)
     n = 20000
@@ -593,6 +595,26 @@ def test_three_estimators_have_one_expectation(pa, cornell):
               f"means {imgs[a].mean():.5f} {imgs[b].mean():.5f}")
         assert np.median(rel) <= 0.015
     assert abs(imgs[0].mean() - imgs[2].mean()) <= 0.01 * imgs[0].mean()
+
+
+def test_long_paths_in_a_closed_box(pa, ob, cornell):
+    """64 segments per path without next-event estimation (the reference's estimator) in the Cornell box: paths end by
+    roulette or on the lamp, the queues ping-pong 64 times, and the image still equals the oracle's."""
+    w, h, spp = 48, 48, 3
+    wf = make_wf(pa, cornell, nee=0, rng_mode=1)
+    wf.allocate(w, h, sky=(0, 0, 0, 1))
+    fs, _ = cornell.camera((0, 1, 3.4), (0, 1, 0), w, h, use_scene=True, frames=5, samples=5)
+    wf.invoke(fs, spp=spp, max_bounces=64)
+    img = wf.read_image()
+    st = wf.stats()
+    osum, ost = cornell.render(ob.render_state(w, h, sky=(0, 0, 0, 1)), fs, ob.path_config(64, 0, 1), spp, threads=8)
+    assert st["extend_rays"] == ost["extend_rays"] and st["extend_rays"] > 3 * spp * w * h // 2
+    finite = np.isfinite(osum).all(axis=2)
+    assert np.array_equal(np.isfinite(img).all(axis=2), finite)
+    assert np.array_equal(bits(img)[finite], bits(osum / np.float32(spp))[finite])
+    with pytest.raises(pa.PtError):
+        wf.invoke(fs, spp=1, max_bounces=65)
+    wf.close()
 
 
 def test_traversal_counters_match_oracle(pa, ob, bundled):
