@@ -372,6 +372,48 @@ def test_random_scenes_of_many_sizes(pa, ob):
     wf.close()
 
 
+def test_deep_tree_uses_the_spilled_stack(pa, ob):
+    """Triangles on a geometric progression along x give a chain-like tree (depth > 40).  Rays that run along the chain,
+    almost parallel to the axis, pass through every box and push more entries than the 10 a lane keeps in LDS, so the
+    scratch part of the stack carries real traffic.  Hits and occlusion must still equal the oracle's, with no overflow."""
+    n = 120
+    x = (2.0 ** np.arange(n)).astype(np.float32)
+    tris = np.zeros(n, ob.TRIANGLE)
+    for name, off in (("v1", (0, 0, -0.15)), ("v2", (0, 0.3, -0.15)), ("v3", (0, 0, 0.15))):   # across the axis
+        p = np.zeros((n, 3), np.float32)
+        p[:, 0] = x
+        tris[name]["position"] = p + np.float32(off)
+        tris[name]["normal"] = (1, 0, 0)
+    s = ob.Scene("")
+    s.set_materials(np.zeros(1, ob.MATERIAL))
+    s.add_triangles(tris)
+    s.build()
+    assert s.counts()["max_depth"] > 40
+    mats, t2, nodes = s.arrays()
+    wf = pa.Wavefront(traversal_stats=True)
+    wf.upload_scene(mats, t2, nodes)
+    rng = np.random.default_rng(9)
+    m = 4096
+    rays = np.zeros((m, 6), np.float32)
+    forward = rng.random(m) < 0.5
+    rays[:, 0] = np.where(forward, -rng.uniform(0.5, 100, m), x[rng.integers(10, 100, m)] * 1.5)
+    rays[:, 1] = rng.uniform(0.001, 0.12, m)
+    rays[:, 2] = rng.uniform(-0.14, 0.02, m)
+    rays[:, 3] = np.where(forward, 1.0, -1.0)
+    rays[:, 4] = rng.uniform(-1, 1, m) * 1e-30           # tiny but not special: the ray stays inside the chain's boxes
+    rays[:, 5] = np.where(rng.random(m) < 0.5, 2e-37, -2e-37)
+    g = wf.trace_closest(rays)
+    can = s.intersect(rays, "canonical", stats=True)
+    assert np.array_equal(g["tri"], can["tri"]) and np.array_equal(bits(g["t"]), bits(can["t"]))
+    assert (g["tri"] >= 0).sum() > m // 4
+    assert can["stats"]["steps"] > 12 * m                # the rays really walk the chain
+    tmax = np.where(forward, rng.uniform(0.5, 300, m), x[rng.integers(10, 100, m)]).astype(np.float32)
+    assert np.array_equal(wf.trace_occluded(rays, tmax), s.occluded(rays, tmax))
+    st = wf.stats()
+    assert st["stack_overflows"] == 0 and st["special_rays"] == 0
+    wf.close()
+
+
 def test_big_leaves(pa, ob):
     """Coincident triangles cannot be split by SAH: leaves of 150 and 17 triangles (beyond the 15 a packed
     stack entry holds, and the larger one beyond the 64 triangles one leaf phase deals) next to ordinary ones; ties among
