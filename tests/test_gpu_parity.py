@@ -672,9 +672,10 @@ def test_traversal_counters_match_oracle(pa, ob, bundled):
     wf.close()
 
 
-def test_batch_size_and_accumulation_invariance(pa, bundled):
-    """The image must not depend on how many samples are traced concurrently, nor on call splitting."""
-    w, h = 96, 64
+@pytest.mark.parametrize("w,h", [(96, 64), (90, 50)])
+def test_batch_size_and_accumulation_invariance(pa, bundled, w, h):
+    """The image must not depend on how many samples are traced concurrently, nor on call splitting (whole 8x8 groups, and a
+    ragged size whose batches take the cleared-plane path)."""
     imgs = []
     for batch, calls in [(1, [4]), (4, [4]), (3, [4]), (2, [1, 3])]:
         wf = make_wf(pa, bundled, nee=True, rng_mode=1, samples_per_batch=batch)
