@@ -219,13 +219,14 @@ def main():
         avg_ms = st["ms_extend"] / ext_launches
         bytes_per_launch = b_ray * st["extend_rays"] / ext_launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        traffic = valu_busy = None      # from the committed PMC passes of this workload (profiles/traffic.json), not measured by this run
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("extend_hbm_bytes_per_launch")
+                pmc = json.load(open(tpath)).get(args.workload, {})
+                traffic, valu_busy = pmc.get("extend_hbm_bytes_per_launch"), pmc.get("valu_busy")
             except Exception:
-                traffic = None
+                traffic = valu_busy = None
         out = {
             "metric": "Mrays/s (primary+bounce+shadow rays traced)", "value": (extend_rays + shadow_rays) / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -236,7 +237,7 @@ def main():
                        "rays_per_step": (extend_rays + shadow_rays) / args.steps,
                        "extend_rays_per_step": extend_rays / args.steps, "shadow_rays_per_step": shadow_rays / args.steps},
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "frac": achieved / 8000.0, "traffic": traffic, "valu_busy": valu_busy,
                          "bytes_per_ray": b_ray, "bvh_steps_per_ray": steps_per_ray, "tri_tests_per_ray": tris_per_ray,
                          "shadow_bvh_steps_per_ray": sh_steps_per_ray, "shadow_tri_tests_per_ray": sh_tris_per_ray,
                          "launches": ext_launches, "avg_launch_ms": avg_ms, "rays_per_launch": st["extend_rays"] / ext_launches,

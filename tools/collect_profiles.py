@@ -32,6 +32,8 @@ def main():
     b["extend_hbm_bytes_per_launch"], b["read_bytes_per_launch"], b["write_bytes_per_launch"] = rd + wr, rd, wr
     b["tcc_hit_rate"] = vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])
     b["method"] = re.sub(r"read [\d.]+ MB in its own pass", "read %.1f MB in its own pass" % (vals["FETCH_SIZE"] * 1024 / 1e6), b["method"])
+    b["valu_busy"] = vals["SQ_INSTS_VALU"] * 4 / (1024 * vals["GRBM_GUI_ACTIVE"] / 8)
+    b["valu_busy_method"] = "SQ_INSTS_VALU (wave instructions, 4 cycles each on a 16-lane SIMD) over 1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs, k_extend<false>, mean per dispatch"
     json.dump(t, open(tpath, "w"), indent=1)
     shutil.copy(os.path.join(out, "final_pmc_summary.txt"), os.path.join(prof, f"{tag}_bench_bundled_pmc.txt"))
     stats = sorted(glob.glob(os.path.join(out, "final_pmc", "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
@@ -40,6 +42,7 @@ def main():
         shutil.copy(os.path.join(out, "final_cfg", w + ".json"), os.path.join(prof, f"{tag}_cfg_{w}.json"))
     d = json.load(open(os.path.join(out, "final_cfg", "bundled.json")))
     d["roofline"]["traffic"] = rd + wr          # the bench line read the previous traffic.json
+    d["roofline"]["valu_busy"] = b["valu_busy"]
     open(os.path.join(prof, f"{tag}_bench_bundled.json"), "w").write(json.dumps(d) + "\n")
     table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_configs_md.py"), os.path.join(out, "final_cfg")], capture_output=True, text=True, check=True).stdout
     cpath = os.path.join(prof, f"{tag}_configs.md")
