@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Copy one round's measured summaries from gpurun_out/ into profiles/ (run here after the GPU call).
+"""Copy a set of measured summaries from gpurun_out/ into profiles/ under a tag (run here after the GPU call).
 
 The GPU call:   tools/pmc_bench.sh gpurun_out/final_pmc > gpurun_out/final_pmc_summary.txt
                 python bench.py > gpurun_out/final_cfg/bundled.json; python bench.py --workload c1|c3|c4|c5 ... > gpurun_out/final_cfg/<w>.json
-Then:           python tools/collect_profiles.py r01
+Then:           python tools/collect_profiles.py <tag>
 """
 import glob
 import json

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Table of every benchmark configuration from the bench lines of one round.
+"""Table of every benchmark configuration from a directory of bench lines.
 
-  python tools/make_configs_md.py <dir with bundled.json c1.json c3.json c4.json c5.json> > profiles/rNN_configs.md
+  python tools/make_configs_md.py <dir with bundled.json c1.json c3.json c4.json c5.json> > profiles/<tag>_configs.md
 """
 import json
 import os
