@@ -59,7 +59,7 @@ struct pt_ctx {
     pt_stats host_stats{};
     // idle lanes a traversal wave collects before it fetches new rays: camera rays of a tile finish together, so waiting for
     // most of the wave costs little and saves refills; scattered rays finish at very different times
-    int refill_primary = 48, refill_bounce = 32;
+    int refill_primary = 48, refill_bounce = 40;
     uint64_t local_pixels = 0;
     int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
 };
