@@ -126,6 +126,11 @@ class Scene:
     def build(self):
         _chk(lib().orc_scene_build(self.h))
 
+    def set_built(self, mats, tris, nodes):
+        """Install arrays another builder produced (built order) without building: for trees beyond the literal build's reach."""
+        mats, tris, nodes = np.ascontiguousarray(mats, MATERIAL), np.ascontiguousarray(tris, TRIANGLE), np.ascontiguousarray(nodes, NODE)
+        _chk(lib().orc_scene_set_built(self.h, _p(mats), mats.size, _p(tris), tris.size, _p(nodes), nodes.size))
+
     def counts(self):
         out = np.zeros(6, np.int32)
         _chk(lib().orc_scene_counts(self.h, _p(out)))

@@ -156,6 +156,24 @@ int orc_scene_build(void* h) {
     ORC_CATCH
 }
 
+// Installs arrays some other builder produced (Material[], Triangle[] in built order, Node[]) without building, so the
+// oracle's walks can run over trees too large for its one-thread literal build.  The arrays are taken as they are.
+int orc_scene_set_built(void* h, const void* mats48, int nMat, const void* tris112, int nTri, const void* nodes32, int nNodes) {
+    ORC_TRY
+    OrcScene* s = (OrcScene*)h;
+    s->scene.Clear();
+    s->scene.materials.resize(nMat);
+    memcpy(s->scene.materials.data(), mats48, (size_t)nMat * 48);
+    auto& a = s->scene.accelerator;
+    a.triangles.resize(nTri);
+    memcpy(a.triangles.data(), tris112, (size_t)nTri * 112);
+    a.nodes.resize(nNodes);
+    memcpy(a.nodes.data(), nodes32, (size_t)nNodes * 32);
+    s->lights = BuildLightTable(s->scene);
+    s->built = true;
+    ORC_CATCH
+}
+
 // counts: materials, triangles (post build), nodes, references (pre build), max depth, lights
 int orc_scene_counts(void* h, int32_t* out6) {
     OrcScene* s = (OrcScene*)h;

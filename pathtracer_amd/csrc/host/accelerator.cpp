@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cmath>
 #include <limits>
+#include <stdexcept>
 #include <thread>
 
 namespace pth {
@@ -114,6 +115,9 @@ bool Accelerator::partition(const Box& bounds, int first, int count, Scratch& sc
         const uint32_t id = order[first + i];
         const float c = axisOf(centroids[id], axis);
         const float b = (c - k0) * k1;
+        // a non-finite vertex makes b NaN or infinite: the reference's buckets[j] raises IndexOutOfRangeException there
+        // (Accelerator.cs:218-222); here the C boundary turns the exception into an error return
+        if (!(b >= 0.0f && b < (float)kBuckets)) throw std::runtime_error("Accelerator.Build: a primitive's centroid is not finite");
         const int j = (int)b;
         sc.bin[i] = (uint8_t)j;
         counts[j]++;

@@ -678,6 +678,28 @@ int pth_scene_load(pth_scene* s, const char* path) {
         }
         std::fclose(f);
         if (!ok) throw std::runtime_error(std::string(path) + " is not a scene cache file");
+        // the arrays go straight into Accelerator.Intersect's loops: every index they hold must be in range
+        for (const Triangle& tri : t)
+            if (tri.Material < 0 || tri.Material >= head[0]) throw std::runtime_error(std::string(path) + ": a triangle's material index is out of range");
+        {
+            std::vector<uint8_t> seen(n.size(), 0);
+            seen[0] = 1;
+            long long covered = 0;
+            for (size_t i = 0; i < n.size(); i++) {
+                const Node& nd = n[i];
+                if (!seen[i]) throw std::runtime_error(std::string(path) + ": a node is not referenced by an earlier node");
+                if (nd.Count > 0) {
+                    if (nd.LeftFirst < 0 || (long long)nd.LeftFirst + nd.Count > head[1]) throw std::runtime_error(std::string(path) + ": a leaf's triangle range is out of bounds");
+                    covered += nd.Count;
+                } else if (head[1] > 0) {
+                    const long long l = nd.LeftFirst;
+                    if (l <= (long long)i || (l & 1) == 0 || l + 1 >= (long long)n.size() || seen[l] || seen[l + 1])
+                        throw std::runtime_error(std::string(path) + ": an interior node's children are out of order or out of bounds");
+                    seen[l] = seen[l + 1] = 1;
+                }
+            }
+            if (head[1] > 0 && covered != head[1]) throw std::runtime_error(std::string(path) + ": the leaves do not cover the triangles exactly once");
+        }
         s->materials.swap(m);
         s->accelerator.Clear();
         for (const Triangle& tri : t) s->accelerator.AddTriangle(tri);   // insertion order := built order (a rebuild keeps working)

@@ -89,10 +89,19 @@ void freeScene(pt_ctx* c) {
 int allocQueues(pt_ctx* c, uint32_t capacity) {
     for (void* p : c->qmem) (void)hipFree(p);
     c->qmem.clear();
+    // nothing may keep pointing at the freed columns if an allocation below fails
+    c->q = Queues{};
+    c->capacity = 0;
     float4** cols[] = {&c->q.o[0], &c->q.o[1], &c->q.d[0], &c->q.d[1], &c->q.T[0], &c->q.T[1], &c->q.hit, &c->q.so, &c->q.sd, &c->q.sc, &c->q.plane};
     for (float4** col : cols) {
         void* p = nullptr;
-        HIPCHECK(c, hipMalloc(&p, (size_t)capacity * sizeof(float4)));
+        const hipError_t e = hipMalloc(&p, (size_t)capacity * sizeof(float4));
+        if (e != hipSuccess) {
+            for (void* m : c->qmem) (void)hipFree(m);
+            c->qmem.clear();
+            c->q = Queues{};
+            FAIL(c, (e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "ray queues of %u paths: %s", capacity, hipGetErrorString(e));
+        }
         c->qmem.push_back(p);
         *col = (float4*)p;
     }
@@ -785,109 +794,118 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
     if (nodes_out && node_capacity < need) FAIL(c, PT_E_INVALID_ARG, "pt_build_scene: room for %d nodes, %d triangles may need %d", node_capacity, n_tri, need);
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
-    freeScene(c);
     const uint32_t n = (uint32_t)n_tri;
-    ptbuild::Tri112 *d_in = nullptr, *d_sorted = nullptr, *d_lightTris = nullptr;
-    ptbuild::Node32* d_nodes = nullptr;
-    ptbuild::BNode* bn = nullptr;
-    uint32_t *d_flagA = nullptr, *d_idxA = nullptr, *d_flagB = nullptr, *d_idxB = nullptr, *d_bad = nullptr;
-    void* tmp = nullptr;
+    // Everything is built into buffers of this call; the context's scene is replaced only when all of it exists, and
+    // the destructor releases whatever is still held on any way out (error returns and exceptions alike).
+    struct Work {
+        pt_ctx* c;
+        ptbuild::Tri112 *d_in = nullptr, *d_sorted = nullptr, *d_lightTris = nullptr;
+        ptbuild::Node32* d_nodes = nullptr;
+        ptbuild::BNode* bn = nullptr;
+        uint32_t *d_flagA = nullptr, *d_idxA = nullptr, *d_flagB = nullptr, *d_idxB = nullptr, *d_bad = nullptr;
+        void* tmp = nullptr;
+        void *pairs = nullptr, *quads = nullptr, *big = nullptr, *hot = nullptr, *cold = nullptr, *mats = nullptr, *lights = nullptr;   // the new scene
+        hipEvent_t ea = nullptr, eb = nullptr;
+        explicit Work(pt_ctx* ctx) : c(ctx) {}
+        ~Work() {
+            void* all[] = {d_in, d_sorted, d_lightTris, d_nodes, bn, d_flagA, d_idxA, d_flagB, d_idxB, d_bad, tmp, pairs, quads, big, hot, cold, mats, lights};
+            for (void* p : all) if (p) (void)hipFree(p);
+            if (ea) c->pool.push_back(ea);
+            if (eb) c->pool.push_back(eb);
+        }
+    } w(c);
     size_t tmpBytes = 0;
-    auto cleanup = [&]() {
-        (void)hipFree(d_in); (void)hipFree(d_sorted); (void)hipFree(d_lightTris); (void)hipFree(d_nodes); (void)hipFree(bn);
-        (void)hipFree(d_flagA); (void)hipFree(d_idxA); (void)hipFree(d_flagB); (void)hipFree(d_idxB); (void)hipFree(d_bad); (void)hipFree(tmp);
-    };
-#define TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); freeScene(c); FAIL(c, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s", #call, hipGetErrorString(_e)); } } while (0)
+#define TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { FAIL(c, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s", #call, hipGetErrorString(_e)); } } while (0)
     if (n) {
-        TRY(hipMalloc((void**)&d_in, (size_t)n * 112));
-        TRY(hipMalloc((void**)&d_sorted, (size_t)n * 112));
-        TRY(hipMemcpyAsync(d_in, triangles_in, (size_t)n * 112, hipMemcpyHostToDevice, c->stream));
+        TRY(hipMalloc((void**)&w.d_in, (size_t)n * 112));
+        TRY(hipMalloc((void**)&w.d_sorted, (size_t)n * 112));
+        TRY(hipMemcpyAsync(w.d_in, triangles_in, (size_t)n * 112, hipMemcpyHostToDevice, c->stream));
     }
-    TRY(hipMalloc((void**)&d_nodes, (size_t)need * 32));
-    hipEvent_t ea = getEvent(c), eb = getEvent(c);
-    if (ea) (void)hipEventRecord(ea, c->stream);
+    TRY(hipMalloc((void**)&w.d_nodes, (size_t)need * 32));
+    w.ea = getEvent(c);
+    w.eb = getEvent(c);
+    if (w.ea) (void)hipEventRecord(w.ea, c->stream);
     uint32_t nn = 0, levels = 0;
-    TRY(ptbuild::build(c->stream, d_in, n, d_nodes, d_sorted, &nn, &levels, &bn));
-    (void)hipFree(d_in);
-    d_in = nullptr;
-    if ((int)levels > PT_STACK_TOTAL || 3 * (((int)levels + 1) / 2) > PT_STACK_TOTAL) {
-        cleanup();
+    TRY(ptbuild::build(c->stream, w.d_in, n, w.d_nodes, w.d_sorted, &nn, &levels, &w.bn));
+    (void)hipFree(w.d_in);
+    w.d_in = nullptr;
+    if ((int)levels > PT_STACK_TOTAL || 3 * (((int)levels + 1) / 2) > PT_STACK_TOTAL)
         FAIL(c, PT_E_BAD_BVH, "BVH depth %u exceeds the traversal stack (%d entries)", levels, PT_STACK_TOTAL);
-    }
     const size_t flagsLen = std::max<size_t>(std::max<size_t>(n, nn), 1);
-    TRY(hipMalloc((void**)&d_flagA, flagsLen * 4));
-    TRY(hipMalloc((void**)&d_idxA, flagsLen * 4));
-    TRY(hipMalloc((void**)&d_flagB, flagsLen * 4));
-    TRY(hipMalloc((void**)&d_idxB, flagsLen * 4));
-    TRY(hipMalloc((void**)&d_bad, 4));
-    TRY(hipMemsetAsync(d_bad, 0, 4, c->stream));
+    TRY(hipMalloc((void**)&w.d_flagA, flagsLen * 4));
+    TRY(hipMalloc((void**)&w.d_idxA, flagsLen * 4));
+    TRY(hipMalloc((void**)&w.d_flagB, flagsLen * 4));
+    TRY(hipMalloc((void**)&w.d_idxB, flagsLen * 4));
+    TRY(hipMalloc((void**)&w.d_bad, 4));
+    TRY(hipMemsetAsync(w.d_bad, 0, 4, c->stream));
     if (n_mat) {
-        TRY(hipMalloc(&c->d_mats, (size_t)n_mat * 48));
-        TRY(hipMemcpyAsync(c->d_mats, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, c->stream));
+        TRY(hipMalloc(&w.mats, (size_t)n_mat * 48));
+        TRY(hipMemcpyAsync(w.mats, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, c->stream));
     }
     // ---- triangles: hot / cold records, the light table
     std::vector<float4> lights;
     float lightSum = 0.0f;
     if (n) {
-        TRY(hipMalloc(&c->d_hot, (size_t)n * 48));
-        TRY(hipMalloc(&c->d_cold, (size_t)n * 48));
-        hipLaunchKernelGGL(ptrepack::k_triangles, dim3(launchGrid(n)), dim3(256), 0, c->stream, d_sorted, n, (const float4*)c->d_mats, n_mat,
-                           (float4*)c->d_hot, (float4*)c->d_cold, d_flagA, d_bad);
-        TRY(ptrepack::exclusiveScan(c->stream, d_flagA, d_idxA, n, &tmp, &tmpBytes));
+        TRY(hipMalloc(&w.hot, (size_t)n * 48));
+        TRY(hipMalloc(&w.cold, (size_t)n * 48));
+        hipLaunchKernelGGL(ptrepack::k_triangles, dim3(launchGrid(n)), dim3(256), 0, c->stream, w.d_sorted, n, (const float4*)w.mats, n_mat,
+                           (float4*)w.hot, (float4*)w.cold, w.d_flagA, w.d_bad);
+        TRY(ptrepack::exclusiveScan(c->stream, w.d_flagA, w.d_idxA, n, &w.tmp, &tmpBytes));
         uint32_t lastFlag = 0, lastIdx = 0, bad = 0;
-        TRY(hipMemcpyAsync(&lastFlag, d_flagA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&lastIdx, d_idxA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&lastFlag, w.d_flagA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&lastIdx, w.d_idxA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&bad, w.d_bad, 4, hipMemcpyDeviceToHost, c->stream));
         TRY(hipStreamSynchronize(c->stream));
-        if (bad) { cleanup(); freeScene(c); FAIL(c, PT_E_INVALID_ARG, "a triangle has a material index outside [0, %d)", n_mat); }
+        if (bad) FAIL(c, PT_E_INVALID_ARG, "a triangle has a material index outside [0, %d)", n_mat);
         const uint32_t nLights = lastFlag + lastIdx;
         if (nLights) {
-            TRY(hipMalloc((void**)&d_lightTris, (size_t)nLights * 112));
-            hipLaunchKernelGGL(ptrepack::k_collect_lights, dim3(launchGrid(n)), dim3(256), 0, c->stream, d_sorted, n, d_flagA, d_idxA, d_lightTris);
+            TRY(hipMalloc((void**)&w.d_lightTris, (size_t)nLights * 112));
+            hipLaunchKernelGGL(ptrepack::k_collect_lights, dim3(launchGrid(n)), dim3(256), 0, c->stream, w.d_sorted, n, w.d_flagA, w.d_idxA, w.d_lightTris);
             std::vector<HostTriangle> lt(nLights);
-            TRY(hipMemcpyAsync(lt.data(), d_lightTris, (size_t)nLights * 112, hipMemcpyDeviceToHost, c->stream));
+            TRY(hipMemcpyAsync(lt.data(), w.d_lightTris, (size_t)nLights * 112, hipMemcpyDeviceToHost, c->stream));
             TRY(hipStreamSynchronize(c->stream));
             for (const HostTriangle& t : lt) appendLight(t, lights, lightSum);   // triangle order: the running sum rounds as on the CPU path
-            TRY(hipMalloc(&c->d_lights, lights.size() * sizeof(float4)));
-            TRY(hipMemcpyAsync(c->d_lights, lights.data(), lights.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+            TRY(hipMalloc(&w.lights, lights.size() * sizeof(float4)));
+            TRY(hipMemcpyAsync(w.lights, lights.data(), lights.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         }
     }
     // ---- nodes: pair records, quad records, big-leaf rows
     uint32_t nQuads = 0, nBig = 0;
     {
-        hipLaunchKernelGGL(ptrepack::k_flags, dim3(launchGrid(nn)), dim3(256), 0, c->stream, bn, nn, d_flagA, d_flagB);
-        TRY(ptrepack::exclusiveScan(c->stream, d_flagA, d_idxA, nn, &tmp, &tmpBytes));
-        TRY(ptrepack::exclusiveScan(c->stream, d_flagB, d_idxB, nn, &tmp, &tmpBytes));
+        hipLaunchKernelGGL(ptrepack::k_flags, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_flagA, w.d_flagB);
+        TRY(ptrepack::exclusiveScan(c->stream, w.d_flagA, w.d_idxA, nn, &w.tmp, &tmpBytes));
+        TRY(ptrepack::exclusiveScan(c->stream, w.d_flagB, w.d_idxB, nn, &w.tmp, &tmpBytes));
         uint32_t v[4] = {0, 0, 0, 0};
-        TRY(hipMemcpyAsync(&v[0], d_flagA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&v[1], d_idxA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&v[2], d_flagB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&v[3], d_idxB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&v[0], w.d_flagA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&v[1], w.d_idxA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&v[2], w.d_flagB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&v[3], w.d_idxB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
         TRY(hipStreamSynchronize(c->stream));
         nQuads = v[0] + v[1];
         nBig = v[2] + v[3];
-        if (nBig >= PT_LEAF_MAX_FIRST) { cleanup(); freeScene(c); FAIL(c, PT_E_BAD_BVH, "%u leaves of more than %d triangles", nBig, PT_LEAF_MAX_COUNT); }
-        if (nn > 1) TRY(hipMalloc(&c->d_pairs, (size_t)(nn - 1) * 32));
-        if (nQuads) TRY(hipMalloc(&c->d_quads, (size_t)nQuads * 128));
-        if (nBig) TRY(hipMalloc(&c->d_big, (size_t)nBig * 8));
-        hipLaunchKernelGGL(ptrepack::k_records, dim3(launchGrid(nn)), dim3(256), 0, c->stream, bn, nn, d_idxA, d_idxB, d_flagB, (float4*)c->d_pairs,
-                           (float4*)c->d_quads, (uint2*)c->d_big);
+        if (nBig >= PT_LEAF_MAX_FIRST) FAIL(c, PT_E_BAD_BVH, "%u leaves of more than %d triangles", nBig, PT_LEAF_MAX_COUNT);
+        if (nn > 1) TRY(hipMalloc(&w.pairs, (size_t)(nn - 1) * 32));
+        if (nQuads) TRY(hipMalloc(&w.quads, (size_t)nQuads * 128));
+        if (nBig) TRY(hipMalloc(&w.big, (size_t)nBig * 8));
+        hipLaunchKernelGGL(ptrepack::k_records, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_idxA, w.d_idxB, w.d_flagB, (float4*)w.pairs,
+                           (float4*)w.quads, (uint2*)w.big);
     }
     ptbuild::BNode root;
-    TRY(hipMemcpyAsync(&root, bn, sizeof(root), hipMemcpyDeviceToHost, c->stream));
-    if (eb) (void)hipEventRecord(eb, c->stream);
-    if (triangles_out && n) TRY(hipMemcpyAsync(triangles_out, d_sorted, (size_t)n * 112, hipMemcpyDeviceToHost, c->stream));
-    if (nodes_out) TRY(hipMemcpyAsync(nodes_out, d_nodes, (size_t)nn * 32, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipMemcpyAsync(&root, w.bn, sizeof(root), hipMemcpyDeviceToHost, c->stream));
+    if (w.eb) (void)hipEventRecord(w.eb, c->stream);
+    if (triangles_out && n) TRY(hipMemcpyAsync(triangles_out, w.d_sorted, (size_t)n * 112, hipMemcpyDeviceToHost, c->stream));
+    if (nodes_out) TRY(hipMemcpyAsync(nodes_out, w.d_nodes, (size_t)nn * 32, hipMemcpyDeviceToHost, c->stream));
     TRY(hipGetLastError());
     TRY(hipStreamSynchronize(c->stream));
 #undef TRY
     if (build_ms) {
         *build_ms = 0.0f;
-        if (ea && eb) (void)hipEventElapsedTime(build_ms, ea, eb);
+        if (w.ea && w.eb) (void)hipEventElapsedTime(build_ms, w.ea, w.eb);
     }
-    if (ea) c->pool.push_back(ea);
-    if (eb) c->pool.push_back(eb);
-    cleanup();
+    // ---- success: the new scene replaces the old one
+    freeScene(c);
+    c->d_pairs = w.pairs; c->d_quads = w.quads; c->d_big = w.big; c->d_hot = w.hot; c->d_cold = w.cold; c->d_mats = w.mats; c->d_lights = w.lights;
+    w.pairs = w.quads = w.big = w.hot = w.cold = w.mats = w.lights = nullptr;
     DevScene& sc = c->sc;
     sc.pairs = (const float4*)c->d_pairs;
     sc.quads = (const float4*)c->d_quads;

@@ -552,7 +552,11 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     PTB_TRY(hipGetLastError());
     PTB_TRY(hipStreamSynchronize(stream));
     *n_nodes_out = h.nodes;
-    if (levels_out) *levels_out = (uint32_t)levelStart.size() - 1u;
+    if (levels_out) {   // levels that hold nodes: the last round of the loop adds an empty one when none of its nodes split
+        uint32_t levels = 0;
+        for (size_t l = 0; l + 1 < levelStart.size(); l++) levels += levelStart[l + 1] > levelStart[l] ? 1u : 0u;
+        *levels_out = levels;
+    }
     if (keep_nodes) { *keep_nodes = nodes; nodes = nullptr; }
 done:
     (void)hipFree(pmin); (void)hipFree(pmax); (void)hipFree(cent);
