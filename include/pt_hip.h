@@ -121,6 +121,15 @@ int pt_trace_closest(pt_ctx* ctx, const float* o_d, int32_t n, int32_t* tri, flo
 /* Any hit with 0 < t < tmax[i] (the connect stage's query).  No reference counterpart: the reference has no shadow rays. */
 int pt_trace_occluded(pt_ctx* ctx, const float* o_d, const float* tmax, int32_t n, uint8_t* occluded);
 
+/* pt_trace_closest for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments and results as
+ * pt_trace_closest, but the rays and hits are staged in a fixed device array of the library (40 bytes per ray,
+ * PT_NOALLOC_MAX_RAYS rays = 2.5 MiB held on every GPU the library runs on until the process ends) instead of buffers
+ * allocated per call: the call makes no hipMalloc / hipFree.  n > PT_NOALLOC_MAX_RAYS is PT_E_INVALID_ARG.  All calls
+ * on one GPU share that array: calls that overlap on one GPU (two contexts, two threads) race. */
+#define PT_NOALLOC_MAX_RAYS 65536
+int pt_trace_closest_noalloc(pt_ctx* ctx, const float* o_d, int32_t n, int32_t* tri, float* t, float* uv);
+
 /* Runs the generate stage alone (generate.glsl:170-200) for local thread indices [0,n) of one sample and copies the
  * rays back: o_d n x 6, pixel n (0xFFFFFFFF where the thread emits no ray).  Parity/debug entry. */
 int pt_generate_rays(pt_ctx* ctx, const void* frame_state112, int32_t n, float* o_d, uint32_t* pixel);

@@ -42,7 +42,8 @@ PT_OPT_NEE, PT_OPT_RNG_MODE, PT_OPT_TRAVERSAL_STATS, PT_OPT_STAGE_TIMING, PT_OPT
 PT_HIP_SYMBOLS = ["pt_default_config", "pt_create", "pt_destroy", "pt_last_error", "pt_upload_scene", "pt_resize",
                   "pt_set_render_state", "pt_reset_accumulation", "pt_render", "pt_synchronize", "pt_read_image",
                   "pt_trace_closest", "pt_trace_occluded", "pt_generate_rays", "pt_get_stats", "pt_reset_stats",
-                  "pt_set_option", "pt_bench_extend", "pt_accum_device", "pt_assemble_tiles", "pt_stream", "pt_build_bvh", "pt_build_scene"]
+                  "pt_set_option", "pt_bench_extend", "pt_accum_device", "pt_assemble_tiles", "pt_stream", "pt_build_bvh", "pt_build_scene",
+                  "pt_trace_closest_noalloc"]
 
 _hip = None
 _host = None
@@ -84,6 +85,7 @@ def hip():
         lib.pt_synchronize.argtypes = [vp]
         lib.pt_read_image.argtypes = [vp, vp]
         lib.pt_trace_closest.argtypes = [vp, vp, i32, vp, vp, vp]
+        lib.pt_trace_closest_noalloc.argtypes = [vp, vp, i32, vp, vp, vp]
         lib.pt_trace_occluded.argtypes = [vp, vp, vp, i32, vp]
         lib.pt_generate_rays.argtypes = [vp, vp, i32, vp, vp]
         lib.pt_bench_extend.argtypes = [vp, vp, i32, i32, C.POINTER(C.c_float), vp, vp]

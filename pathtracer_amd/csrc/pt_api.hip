@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cmath>
 #include <algorithm>
+#include <mutex>
 
 namespace {
 
@@ -27,6 +28,31 @@ static_assert(sizeof(HostRenderState) == 32 && sizeof(HostFrameState) == 112, "h
 
 std::string g_err;   // errors without a context
 
+}  // namespace
+
+// ---- fixed device staging of pt_trace_closest_noalloc -----------------------------------------
+// Rays in and hits out of one call, per ray: origin + direction (24 B), triangle (4 B), distance (4 B), (u, v) (8 B).
+// Every GPU the library runs on holds its own copy of the array, at its own address, until the process ends.
+#define PT_NOALLOC_BYTES ((size_t)PT_NOALLOC_MAX_RAYS * 40)
+static __device__ __align__(256) unsigned char scratch[PT_NOALLOC_BYTES];
+namespace {
+// `scratch` is only a host-side handle for hipGetSymbolAddress; the device address of each GPU's copy is kept here
+// (resolved once per device by pt_create, with that device current) and is what kernels and copies receive.
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+hipError_t resolveScratch(int device, void** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 }  // namespace
 
 struct pt_ctx {
@@ -62,6 +88,7 @@ struct pt_ctx {
     int refill_primary = 48, refill_bounce = 40;
     uint64_t local_pixels = 0;
     int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
+    void* scratch_dev = nullptr;   // this device's copy of the fixed staging array (pt_trace_closest_noalloc)
 };
 
 #define FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); if (ctx) (ctx)->err = _b; else g_err = _b; return (code); } while (0)
@@ -246,6 +273,7 @@ static int impl_create(const pt_config* cfg, pt_ctx** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) FAIL((pt_ctx*)nullptr, PT_E_NO_DEVICE, "pt_create: no HIP device");
     if (cfg->device < 0 || cfg->device >= ndev) FAIL((pt_ctx*)nullptr, PT_E_NO_DEVICE, "pt_create: device %d of %d", cfg->device, ndev);
+    if (cfg->device >= kMaxDevices) FAIL((pt_ctx*)nullptr, PT_E_NO_DEVICE, "pt_create: device ordinal %d is beyond the %d this library keeps state for", cfg->device, kMaxDevices);
     pt_ctx* c = new pt_ctx();
     c->cfg = *cfg;
     hipError_t e = hipSetDevice(cfg->device);
@@ -254,6 +282,7 @@ static int impl_create(const pt_config* cfg, pt_ctx** out) {
     if (e == hipSuccess) e = hipMemset(c->d_ctl, 0, sizeof(Ctl));
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
+    if (e == hipSuccess) e = resolveScratch(cfg->device, &c->scratch_dev);   // with cfg->device current
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, cfg->device);
     if (e != hipSuccess) {
@@ -671,6 +700,34 @@ static int impl_trace_closest(pt_ctx* c, const float* o_d, int32_t n, int32_t* t
 static int impl_trace_occluded(pt_ctx* c, const float* o_d, const float* tmax, int32_t n, uint8_t* occluded) {
     if (n > 0 && (!tmax || !occluded)) return PT_E_INVALID_ARG;
     return traceCommon(c, true, o_d, tmax, n, nullptr, nullptr, nullptr, occluded);
+}
+
+// pt_trace_closest without a single allocation: the rays are staged in, and the hits out of, this device's copy of the
+// fixed `scratch` array (always through c->scratch_dev, the address hipGetSymbolAddress gave for this device).  Every ray
+// of [0, n) is stored by the kernel, so nothing in the array has to start at zero; what a call leaves behind is simply
+// overwritten by the next.  Calls that overlap on one GPU share the array and race.
+int pt_trace_closest_noalloc(pt_ctx* c, const float* o_d, int32_t n, int32_t* tri, float* t, float* uv) {
+    if (!c || n < 0 || (n && !o_d)) return PT_E_INVALID_ARG;
+    if (n > PT_NOALLOC_MAX_RAYS) FAIL(c, PT_E_INVALID_ARG, "pt_trace_closest_noalloc: %d rays, the fixed staging array holds at most %d per call", n, PT_NOALLOC_MAX_RAYS);
+    if (!c->has_scene) FAIL(c, PT_E_STATE, "trace before pt_upload_scene");
+    if (!c->scratch_dev) FAIL(c, PT_E_STATE, "pt_trace_closest_noalloc: the staging array was not resolved on device %d", c->cfg.device);
+    if (n == 0) return PT_OK;
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    unsigned char* const base = (unsigned char*)c->scratch_dev;
+    float* const d_rays = (float*)base;
+    int32_t* const d_tri = (int32_t*)(base + (size_t)PT_NOALLOC_MAX_RAYS * 24);
+    float* const d_t = (float*)(base + (size_t)PT_NOALLOC_MAX_RAYS * 28);
+    float* const d_uv = (float*)(base + (size_t)PT_NOALLOC_MAX_RAYS * 32);
+    HIPCHECK(c, hipMemcpyAsync(d_rays, o_d, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, 0ull);
+    TraceSource src{d_rays, nullptr, d_tri, d_t, uv ? d_uv : nullptr, nullptr};
+    hipLaunchKernelGGL(k_trace<false>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl);
+    HIPCHECK(c, hipGetLastError());
+    if (tri) HIPCHECK(c, hipMemcpyAsync(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (t) HIPCHECK(c, hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (uv) HIPCHECK(c, hipMemcpyAsync(uv, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
 }
 
 static int impl_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, float* o_d, uint32_t* pixel) {

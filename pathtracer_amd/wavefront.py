@@ -103,6 +103,14 @@ class Wavefront:
         self._check(self._lib.pt_trace_closest(self._h, _ptr(rays), n, _ptr(tri), _ptr(t), _ptr(uv)))
         return dict(tri=tri, t=t, uv=uv)
 
+    def trace_closest_noalloc(self, rays):
+        """trace_closest through the entry point that allocates no device memory (at most 65,536 rays per call)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        tri, t, uv = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros((n, 2), np.float32)
+        self._check(self._lib.pt_trace_closest_noalloc(self._h, _ptr(rays), n, _ptr(tri), _ptr(t), _ptr(uv)))
+        return dict(tri=tri, t=t, uv=uv)
+
     def trace_occluded(self, rays, tmax):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         tmax = np.ascontiguousarray(tmax, np.float32)
