@@ -6,17 +6,23 @@ generate -> {extend -> shade -> connect} x bounces on every rank's tiles (scene 
 in HBM; the device-to-host image read is outside the timed region).  Default workload is
 the headline configuration: the reference's bundled scene, 1920x1080, 16 spp, 4 bounces, NEE.
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
 
-With N > 1 the image's 8x8 pixel groups are sharded round-robin over the ranks (scene replicated),
-every rank traces spp*N samples of its groups (weak scaling: fixed rays per GPU), and once per
+starts by itself: with N > 1 and no launcher environment it spawns its N ranks through
+torch.distributed.run as a child process (before anything touches the GPU) and relays the JSON line; started by
+torch.distributed.run (RANK / WORLD_SIZE set) it is one of the ranks.
+
+With N > 1 the image's 8x8 pixel groups are sharded round-robin over the ranks (scene replicated) and once per
 frame the rank-local accumulators are gathered to rank 0 with RCCL inside the timed region.
+  --scaling weak    (default) every rank traces spp*N samples of its groups: fixed rays per GPU
+  --scaling strong  the frame is fixed (spp samples of every pixel), each rank traces its 1/N of the pixels
 Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +41,21 @@ WORKLOADS = {
     "c4": ("bundled recipe + 19 bunnies (259,600 triangles, Sponza-scale), 3840x2160, 256 spp in steps of 32, 4 bounces, NEE", 3840, 2160, 32, 4, 1),
     "c5": ("4,026 instanced bunnies flattened (20.0M triangles), 3840x2160, 1024 spp in steps of 8, 8 bounces, NEE", 3840, 2160, 8, 8, 1),
 }
+
+# Vector-ALU peak the traversal kernels are priced against: one wave64 instruction per SIMD every 4 clocks, i.e. 16 lanes per
+# SIMD and clock, 4 SIMDs x 256 CUs at 2.4 GHz.  Not the 157 TFLOP/s headline: that counts packed two-wide FMAs, and this path
+# may neither fuse (bit-exactness with the C# arithmetic) nor pack (one ray per lane).
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+HBM_PEAK_GBS = 8000.0
+
+
+def host_threads():
+    """Threads for the CPU baseline: the CPUs this job may use (a 1-GPU box grants a share of the machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = os.environ.get("OMP_NUM_THREADS")
+    if share and share.isdigit():
+        n = min(n, int(share))
+    return max(1, n)
 
 
 def build_scene(name, threads):
@@ -55,14 +76,29 @@ def build_scene(name, threads):
     return s
 
 
-def camera_for(name, w, h, wf):
-    from pathtracer_amd.host import Camera
+def view_of(name):
     if name in ("bundled", "c1", "c4"):
         # Game.Initialize sets the camera before the scene exists: focal distance stays 20 (Game.cs:45-51)
-        return Camera(w, h, None), (0, 2, 15), (0, 3, 0)
+        return (0, 2, 15), (0, 3, 0)
     if name == "c5":
-        return Camera(w, h, None), (0, 25, 70), (0, 18, 0)
-    return Camera(w, h, None), (0, 0, 120), (0, 0, 0)
+        return (0, 25, 70), (0, 18, 0)
+    return (0, 0, 120), (0, 0, 0)
+
+
+def count_quads(nodes):
+    """Interior nodes at an even depth = quad records of the device tree (one per two levels)."""
+    if nodes.size == 0 or nodes["count"][0] > 0:
+        return 0
+    level = np.array([0], np.int64)
+    depth, quads = 0, 0
+    while level.size:
+        interior = level[nodes["count"][level] <= 0]
+        if depth % 2 == 0:
+            quads += int(interior.size)
+        left = nodes["left_first"][interior].astype(np.int64)
+        level = np.concatenate([left, left + 1])
+        depth += 1
+    return quads
 
 
 def cpu_baseline(name, w, h, bounces, nee, fs, threads):
@@ -88,10 +124,185 @@ def cpu_baseline(name, w, h, bounces, nee, fs, threads):
     dt1 = time.perf_counter() - t1
     rays1 = st1["extend_rays"] + st1["shadow_rays"]
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{spp} of the frame's samples per pixel, whole image ({rays} rays in {dt:.1f} s on {threads} threads); "
+            "host_cpu_count": os.cpu_count(),
+            "sample": f"{spp} of the frame's samples per pixel, whole image ({rays} rays in {dt:.1f} s on {threads} threads = every CPU this "
+                      f"job may use; os.cpu_count() = {os.cpu_count()} is the whole machine); "
                       f"C++ -O2 restatement of Accelerator.Intersect + shade, which is faster than the C# original",
             "single_thread_value": rays1 / dt1 / 1e6,
             "single_thread_sample": f"1 spp of every {stride}th pixel group ({rays1} rays in {dt1:.1f} s on 1 thread)"}
+
+
+def isa_cost():
+    """VALU instructions per interior iteration / leaf phase of the traversal kernels (tools/isa_cost.py, from the kernels' ISA)."""
+    with open(os.path.join(ROOT, "pathtracer_amd", "isa_cost.json")) as f:
+        return json.load(f)
+
+
+def committed_pmc(workload):
+    """HBM-side traffic and VALU-busy of the extend kernel from the PMC passes committed under profiles/ (NOT measured by this run)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)).get(workload, {})
+    except Exception:
+        return {}
+
+
+class Run:
+    """One workload on this rank's context: scene, camera, step()."""
+
+    def __init__(self, args, name, rank, world, local_rank, spp_override=0, strong=False):
+        import pathtracer_amd as pa
+        from pathtracer_amd import tiles
+        from pathtracer_amd.host import Camera
+        self.name = name
+        self.desc, w, h, spp, bounces, nee = WORKLOADS[name]
+        self.w, self.h = args.width or w, args.height or h
+        self.spp, self.bounces, self.nee = spp_override or args.spp or spp, args.bounces or bounces, nee
+        self.world, self.rank = world, rank
+        self.spp_total = self.spp if strong else self.spp * world
+        scene = build_scene(name, threads=min(16, host_threads()))
+        self.mats, self.tris, self.nodes = scene.arrays()
+        self.wf = pa.Wavefront(device=local_rank, nee=bool(nee), rng_mode=1, tile_rank=rank, tile_world=world,
+                               samples_per_batch=args.batch, stage_timing=1)
+        self.wf.upload_scene(self.mats, self.tris, self.nodes)
+        if args.blocks >= 0:
+            self.wf.set_option(6, args.blocks)
+        if args.refill_primary:
+            self.wf.set_option(7, args.refill_primary)
+        if args.refill_bounce:
+            self.wf.set_option(8, args.refill_bounce)
+        self.wf.allocate(self.w, self.h)
+        self.pos, self.tgt = view_of(name)
+        self.cam = Camera(self.w, self.h, None)
+        self.fs = self.cam.frame_state(self.pos, self.tgt, frames=1, samples=0)
+        self.gather = tiles.AccumulatorGather(self.wf, dst=0) if world > 1 else None
+
+    def step(self):
+        self.wf.invoke(self.fs, spp=self.spp_total, max_bounces=self.bounces, wait=False)
+        self.fs["frames"] += self.spp_total
+        self.fs["samples"] += self.spp_total
+        if self.gather is not None:
+            self.gather()   # the image's tiles to rank 0; RCCL moves them while the next image renders
+
+    def instrumented(self):
+        """One un-timed step with the counting kernels (BVH steps, triangle tests, wave iterations), one with every stage
+        launch bracketed by events (the stage breakdown)."""
+        wf = self.wf
+        wf.set_option(3, 1)
+        wf.reset_stats()
+        self.step()
+        wf.synchronize()
+        counted = wf.stats()
+        wf.set_option(3, 0)
+        wf.set_option(4, 1)
+        wf.reset_stats()
+        self.step()
+        wf.synchronize()
+        staged = wf.stats()
+        return counted, staged
+
+    def close(self):
+        self.wf.close()
+
+
+def traversal_roofline(counted, timed, kernel_cost, n_quads, n_tris, pmc):
+    """The extend kernel against the vector-ALU issue roof, from counts of the instrumented pass and HIP-event times of the timed
+    steps.  Useful lane-operations = BVH steps x VALU instructions of one interior iteration + triangle tests x VALU instructions of
+    one leaf phase: what the walk needs if every lane of every issued instruction did useful work."""
+    i_int, i_leaf = kernel_cost["interior_iteration"]["valu"], kernel_cost["leaf_phase"]["valu"]
+    rays = max(1, counted["extend_rays"])
+    steps_per_ray = counted["extend_steps"] / rays
+    tris_per_ray = counted["extend_tris"] / rays
+    launches = max(1, timed["extend_launches"])
+    avg_ms = timed["ms_extend"] / launches
+    rays_per_launch = timed["extend_rays"] / launches
+    laneops_per_ray = steps_per_ray * i_int + tris_per_ray * i_leaf
+    achieved = laneops_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    lane_int = counted["extend_steps"] / max(1, 64 * counted["sched_interior"])
+    lane_leaf = counted["extend_tris"] / max(1, 64 * counted["sched_leaf"])
+    issued = counted["sched_interior"] * i_int + counted["sched_leaf"] * i_leaf     # wave instructions, the two loops only
+    # HBM: the bytes a launch cannot avoid moving are its ray records (32 in, 16 out) and one pass over the tree and the hot
+    # triangle records; everything else the walk touches is re-use that the caches serve
+    scene_bytes = 128.0 * n_quads + 48.0 * n_tris
+    hbm_alg = 48.0 * rays_per_launch + scene_bytes
+    hbm_achieved = hbm_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    gathered = 128.0 * steps_per_ray + 48.0 * tris_per_ray
+    return {
+        "bound": "valu", "kernel": "k_extend", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+        "frac": achieved / VALU_PEAK_TLANEOPS,
+        "traffic": pmc.get("extend_hbm_bytes_per_launch"),
+        "traffic_source": (pmc.get("source", "profiles/traffic.json") + " (committed PMC passes, not measured by this run)") if pmc else None,
+        "launches": launches, "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch,
+        "valu_instr_per_interior_iteration": i_int, "valu_instr_per_leaf_phase": i_leaf,
+        "bvh_steps_per_ray": steps_per_ray, "tri_tests_per_ray": tris_per_ray, "lane_ops_per_ray": laneops_per_ray,
+        "lane_utilisation": {"interior": lane_int, "leaf": lane_leaf,
+                             "overall": (counted["extend_steps"] * i_int + counted["extend_tris"] * i_leaf) / max(1, 64 * issued)},
+        "issue_model_wave_instr_per_ray": issued / rays,
+        "valu_busy_pmc": pmc.get("valu_busy"),
+        "extend_mrays_per_s": timed["extend_rays"] / max(1e-9, timed["ms_extend"] * 1e-3) / 1e6,
+        # second roof, for the record: HBM.  achieved = the bytes a launch must move (ray records + one pass over the scene) / time;
+        # "gathered" is what the walk reads through the caches (the figure that exceeds the HBM peak: the tree lives in L2)
+        "hbm": {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+                "bytes_per_launch": hbm_alg, "scene_bytes": scene_bytes,
+                "cache_served_bytes_per_ray": gathered,
+                "cache_served_gbs": gathered * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0},
+    }
+
+
+def timed_steps(run, steps, warmup, sync_all):
+    for _ in range(warmup):
+        run.step()
+    sync_all()
+    run.wf.reset_stats()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run.step()
+    sync_all()
+    return time.perf_counter() - t0, run.wf.stats()
+
+
+def secondary_soup(args, cost, steps=3):
+    """The north-star workload beside the headline line: 1M-triangle soup, 1080p, 64 spp, 4 bounces, NEE on this GPU."""
+    run = Run(args_without_overrides(args), "c3", 0, 1, 0)
+    counted, staged = run.instrumented()
+
+    def sync_all():
+        run.wf.synchronize()
+
+    run.wf.set_option(4, 1)   # every stage bracketed: this block reports per-stage rates
+    dt, st = timed_steps(run, steps, 1, sync_all)
+    bounce_rays = st["extend_rays"] - st["paths"]
+    bounce_ms = st["ms_extend"] - st["ms_extend_primary"]
+    roof = traversal_roofline(counted, st, cost["k_extend"], count_quads(run.nodes), int(run.tris.size), committed_pmc("c3"))
+    out = {
+        "workload": run.desc, "steps": steps, "ms_per_frame": dt / steps * 1e3,
+        "mrays_per_s": (st["extend_rays"] + st["shadow_rays"]) / dt / 1e6,
+        "extend_mrays_per_s": st["extend_rays"] / max(1e-9, st["ms_extend"] * 1e-3) / 1e6,
+        "bounce_extend_mrays_per_s": bounce_rays / max(1e-9, bounce_ms * 1e-3) / 1e6,
+        "primary_extend_mrays_per_s": st["paths"] / max(1e-9, st["ms_extend_primary"] * 1e-3) / 1e6,
+        "connect_mrays_per_s": st["shadow_rays"] / max(1e-9, st["ms_connect"] * 1e-3) / 1e6,
+        "stage_ms_per_frame": {k: st["ms_" + k] / steps for k in ("generate", "extend", "shade", "connect")},
+        "rays_per_frame": {"extend": st["extend_rays"] / steps, "bounce": bounce_rays / steps, "shadow": st["shadow_rays"] / steps},
+        "shadow_bvh_steps_per_ray": counted["shadow_steps"] / max(1, counted["shadow_rays"]),
+        "shadow_tri_tests_per_ray": counted["shadow_tris"] / max(1, counted["shadow_rays"]),
+        "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "bvh_steps_per_ray",
+                                           "tri_tests_per_ray", "lane_utilisation")},
+    }
+    run.close()
+    return out
+
+
+def args_without_overrides(args):
+    a = argparse.Namespace(**vars(args))
+    a.width = a.height = a.spp = a.bounces = 0
+    return a
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def main():
@@ -100,6 +311,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="bundled", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -109,22 +321,27 @@ def main():
     ap.add_argument("--refill-primary", type=int, default=0, help="idle lanes a traversal wave collects before fetching camera rays (0 = the library's choice)")
     ap.add_argument("--refill-bounce", type=int, default=0, help="the same for bounce and shadow rays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 1M-triangle soup block of the N = 1 line")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only for rehearsing N > 1 on a single GPU")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
     args = ap.parse_args()
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        # Start the N ranks ourselves, as fresh child processes, before this process has touched the GPU (it never will).
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        return subprocess.run(cmd, env=env).returncode
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be started by torch.distributed.run with N ranks")
-        args.gpus = world
+    args.gpus = world
 
     import torch
     import torch.distributed as dist
-    import pathtracer_amd as pa
-    from pathtracer_amd import tiles
 
     if args.same_device:
         local_rank = 0
@@ -136,34 +353,9 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    desc, w, h, spp, bounces, nee = WORKLOADS[args.workload]
-    w, h = args.width or w, args.height or h
-    spp, bounces = args.spp or spp, args.bounces or bounces
-    spp_total = spp * world
-
-    scene = build_scene(args.workload, threads=8)
-    mats, tris, nodes = scene.arrays()
-    wf = pa.Wavefront(device=local_rank, nee=bool(nee), rng_mode=1, tile_rank=rank, tile_world=world,
-                      samples_per_batch=args.batch, stage_timing=1)
-    wf.upload_scene(mats, tris, nodes)
-    if args.blocks >= 0:
-        wf.set_option(6, args.blocks)
-    if args.refill_primary:
-        wf.set_option(7, args.refill_primary)
-    if args.refill_bounce:
-        wf.set_option(8, args.refill_bounce)
-    wf.allocate(w, h)
-    cam, pos, tgt = camera_for(args.workload, w, h, wf)
-    fs = cam.frame_state(pos, tgt, frames=1, samples=0)
-
-    gather = tiles.AccumulatorGather(wf, dst=0) if world > 1 else None
-
-    def step():
-        wf.invoke(fs, spp=spp_total, max_bounces=bounces, wait=False)
-        fs["frames"] += spp_total
-        fs["samples"] += spp_total
-        if gather is not None:
-            gather()   # the image's tiles to rank 0; RCCL moves them while the next image renders
+    strong = args.scaling == "strong"
+    run = Run(args, args.workload, rank, world, local_rank, strong=strong)
+    wf = run.wf
 
     def sync_all():
         wf.synchronize()
@@ -171,39 +363,13 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # ---- un-timed instrumented pass: BVH steps and triangle tests per ray (the algorithmic bytes)
-    wf.set_option(3, 1)
-    wf.reset_stats()
-    step()
-    wf.synchronize()
-    st = wf.stats()
-    wf.set_option(3, 0)
-    # ---- one un-timed plain pass with events around every stage launch: the stage breakdown
-    wf.reset_stats()
-    step()
-    wf.synchronize()
-    stb = wf.stats()
-    stage_ms = {k: stb["ms_" + k] for k in ("generate", "extend", "shade", "connect")}
+    counted, staged = run.instrumented()
+    stage_ms = {k: staged["ms_" + k] for k in ("generate", "extend", "shade", "connect")}
     wf.set_option(4, 2)   # the timed steps bracket only the extend launches (every pair of events costs stream time)
-    steps_per_ray = st["extend_steps"] / max(1, st["extend_rays"])
-    tris_per_ray = st["extend_tris"] / max(1, st["extend_rays"])
-    sh_steps_per_ray = st["shadow_steps"] / max(1, st["shadow_rays"])
-    sh_tris_per_ray = st["shadow_tris"] / max(1, st["shadow_rays"])
+    dt, st = timed_steps(run, args.steps, args.warmup, sync_all)
 
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    wf.reset_stats()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    dt = time.perf_counter() - t0
-
-    st = wf.stats()
-    red_dev = "cuda" if args.backend == "nccl" else "cpu"
-    tot = torch.tensor([float(st["extend_rays"]), float(st["shadow_rays"]), dt], dtype=torch.float64, device=red_dev)
+    red_dev = "cuda" if (args.backend == "nccl" or world == 1) else "cpu"
+    tot = torch.tensor([float(st["extend_rays"]), float(st["shadow_rays"])], dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -212,56 +378,45 @@ def main():
     dt = tmax[0].item()
 
     if rank == 0:
-        # dominant kernel: extend.  Algorithmic bytes per ray = 32 (origin+direction in) + 16 (hit out)
-        # + 128 per BVH step (one quad record: four boxes and entries) + 48 per triangle test (one hot triangle record).
-        b_ray = 48.0 + 128.0 * steps_per_ray + 48.0 * tris_per_ray
-        ext_launches = max(1, st["extend_launches"])
-        avg_ms = st["ms_extend"] / ext_launches
-        bytes_per_launch = b_ray * st["extend_rays"] / ext_launches
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = valu_busy = None      # from the committed PMC passes of this workload (profiles/traffic.json), not measured by this run
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                pmc = json.load(open(tpath)).get(args.workload, {})
-                traffic, valu_busy = pmc.get("extend_hbm_bytes_per_launch"), pmc.get("valu_busy")
-            except Exception:
-                traffic = valu_busy = None
+        cost = isa_cost()
+        roof = traversal_roofline(counted, st, cost["k_extend"], count_quads(run.nodes), int(run.tris.size), committed_pmc(args.workload))
+        roof["shadow_bvh_steps_per_ray"] = counted["shadow_steps"] / max(1, counted["shadow_rays"])
+        roof["shadow_tri_tests_per_ray"] = counted["shadow_tris"] / max(1, counted["shadow_rays"])
+        bounce_rays = st["extend_rays"] - st["paths"]
+        bounce_ms = st["ms_extend"] - st["ms_extend_primary"]
+        roof["bounce_extend_mrays_per_s"] = bounce_rays / max(1e-9, bounce_ms * 1e-3) / 1e6
+        roof["primary_extend_mrays_per_s"] = st["paths"] / max(1e-9, st["ms_extend_primary"] * 1e-3) / 1e6
+        overridden = args.spp or args.width or args.height or args.bounces
         out = {
             "metric": "Mrays/s (primary+bounce+shadow rays traced)", "value": (extend_rays + shadow_rays) / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc if not (args.spp or args.width or args.bounces) else f"{args.workload} {w}x{h} {spp} spp {bounces} bounces nee={nee}",
-                       "width": w, "height": h, "spp_per_gpu": spp, "spp_total": spp_total, "max_bounces": bounces, "nee": nee,
-                       "triangles": int(tris.size), "nodes": int(nodes.size), "tiles": f"8x8 groups round-robin over {world} rank(s)",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": run.desc if not overridden else f"{args.workload} {run.w}x{run.h} {run.spp} spp {run.bounces} bounces nee={run.nee}",
+                       "width": run.w, "height": run.h, "spp_per_gpu": run.spp, "spp_total": run.spp_total, "max_bounces": run.bounces,
+                       "nee": run.nee, "triangles": int(run.tris.size), "nodes": int(run.nodes.size),
+                       "tiles": f"8x8 groups round-robin over {world} rank(s)",
                        "rays_per_step": (extend_rays + shadow_rays) / args.steps,
                        "extend_rays_per_step": extend_rays / args.steps, "shadow_rays_per_step": shadow_rays / args.steps},
-            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "valu_busy": valu_busy,
-                         "bytes_per_ray": b_ray, "bvh_steps_per_ray": steps_per_ray, "tri_tests_per_ray": tris_per_ray,
-                         "shadow_bvh_steps_per_ray": sh_steps_per_ray, "shadow_tri_tests_per_ray": sh_tris_per_ray,
-                         "launches": ext_launches, "avg_launch_ms": avg_ms, "rays_per_launch": st["extend_rays"] / ext_launches,
-                         "extend_mrays_per_s": st["extend_rays"] / max(1e-9, st["ms_extend"] * 1e-3) / 1e6,
-                         # frac > 1 means the caches, not HBM, serve the algorithmic bytes.  What does bound a gather of random
-                         # records is the rate tools/micro/tcp_coalesce.hip measures (L1/L2-resident table: 196 G records/s,
-                         # Infinity-Cache-resident: 58 G records/s; profiles/r01_micro_gather.txt):
-                         "gather_records_per_s": (steps_per_ray + tris_per_ray) * st["extend_rays"] / max(1e-9, st["ms_extend"] * 1e-3),
-                         "gather_ceiling_records_per_s": {"l2_resident": 196e9, "infinity_cache_resident": 58e9}},
+            "roofline": roof,
             "stage_ms_per_step": stage_ms,   # from one un-timed step with every stage bracketed by events
         }
+        run.close()
         if world == 1 and not args.no_cpu_baseline and args.workload in ("bundled", "c1", "soup1m", "c3"):
-            fs0 = cam.frame_state(pos, tgt, frames=1, samples=0)
-            threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(args.workload, w, h, bounces, nee, fs0, threads)
+            fs0 = run.cam.frame_state(run.pos, run.tgt, frames=1, samples=0)
+            out["cpu_baseline"] = cpu_baseline(args.workload, run.w, run.h, run.bounces, run.nee, fs0, host_threads())
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary and args.workload == "bundled" and not overridden:
+            out["secondary"] = secondary_soup(args, cost)
         print(json.dumps(out), flush=True)
+    else:
+        run.close()
 
-    wf.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -69,7 +69,8 @@ typedef struct pt_stats {
     uint32_t extend_launches, shade_launches, connect_launches, generate_launches;
     float ms_generate, ms_extend, ms_shade, ms_connect;   /* summed event time per stage (stage_timing) */
     float ms_render;            /* wall time of the last pt_render + pt_synchronize pair measured by events */
-    float reserved[3];
+    float ms_extend_primary;    /* the part of ms_extend spent on camera rays (the extend launch of bounce 0; its rays = paths) */
+    float reserved[2];
     /* extend stage, traversal_stats only: iterations a wave spent on interior steps, on leaf (triangle) steps and on
      * retiring/refilling lanes; extend_steps / (64 * sched_interior) is the lane utilisation of the interior loop */
     uint64_t sched_interior, sched_leaf, sched_refill;

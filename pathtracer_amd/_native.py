@@ -28,7 +28,7 @@ class pt_stats(C.Structure):
                 ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("connect_launches", C.c_uint32),
                 ("generate_launches", C.c_uint32),
                 ("ms_generate", C.c_float), ("ms_extend", C.c_float), ("ms_shade", C.c_float), ("ms_connect", C.c_float),
-                ("ms_render", C.c_float), ("reserved", C.c_float * 3),
+                ("ms_render", C.c_float), ("ms_extend_primary", C.c_float), ("reserved", C.c_float * 2),
                 ("sched_interior", C.c_uint64), ("sched_leaf", C.c_uint64), ("sched_refill", C.c_uint64),
                 ("special_rays", C.c_uint64)]
 

@@ -163,7 +163,7 @@ hipEvent_t getEvent(pt_ctx* c) {
 struct StageTimer {
     pt_ctx* c; int stage; hipEvent_t a = nullptr, b = nullptr;
     StageTimer(pt_ctx* ctx, int s) : c(ctx), stage(s) {
-        if (c->cfg.stage_timing == 1 || (c->cfg.stage_timing == 2 && s == 1)) { a = getEvent(c); b = getEvent(c); if (a) (void)hipEventRecord(a, c->stream); }
+        if (c->cfg.stage_timing == 1 || (c->cfg.stage_timing == 2 && (s == 1 || s == 4))) { a = getEvent(c); b = getEvent(c); if (a) (void)hipEventRecord(a, c->stream); }
     }
     ~StageTimer() {
         if (a && b) { (void)hipEventRecord(b, c->stream); c->spans.push_back({a, b, stage}); }
@@ -174,8 +174,10 @@ void collectSpans(pt_ctx* c) {
     for (auto& s : c->spans) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-            float* dst[] = {&c->host_stats.ms_generate, &c->host_stats.ms_extend, &c->host_stats.ms_shade, &c->host_stats.ms_connect};
+            // stage 4 = the extend launch of bounce 0 (camera rays): part of ms_extend, and kept apart as well
+            float* dst[] = {&c->host_stats.ms_generate, &c->host_stats.ms_extend, &c->host_stats.ms_shade, &c->host_stats.ms_connect, &c->host_stats.ms_extend};
             *dst[s.stage] += ms;
+            if (s.stage == 4) c->host_stats.ms_extend_primary += ms;
         }
         c->pool.push_back(s.a);
         c->pool.push_back(s.b);
@@ -562,7 +564,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             rp.bounce = b;
             rp.last_bounce = (b == max_bounces - 1) ? 1 : 0;
             {
-                StageTimer t(c, 1);
+                StageTimer t(c, b == 0 ? 4 : 1);
                 launchExtend(c, stats, cur, (uint32_t)(b == 0 ? c->refill_primary : c->refill_bounce));
                 c->host_stats.extend_launches++;
             }

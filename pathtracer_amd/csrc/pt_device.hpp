@@ -358,6 +358,13 @@ static inline uint32_t packLeaf(int32_t first, int32_t count, uint32_t bigIndex)
 // Lane state: `cur` is the current entry: 0 = no work (ray ended or lane idle), sign bit clear = interior
 // reference, sign bit set = leaf whose remaining triangles are [leafJ, leafEnd).
 #define PT_KEY_MISS 0xFFFFFFFFu
+// Markers for tools/isa_cost.py: with -DPT_ISA_MARKS the assembly carries comments around one interior iteration and one
+// leaf phase, between which the tool counts vector-ALU instructions.  The shipped build has none.
+#ifdef PT_ISA_MARKS
+#define PT_MARK(name) asm volatile("; PT_MARK " name)
+#else
+#define PT_MARK(name)
+#endif
 
 template <bool ANYHIT, bool STATS, class Source>
 __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, unsigned long long* leafq, const Source& src,
@@ -486,6 +493,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             if (interiorMask == 0ull || nLeaf >= PT_LEAF_BATCH) break;
             if (refillable && 64u - (uint32_t)__popcll(interiorMask) - nLeaf >= refillMin) break;
             if (STATS) sched[0]++;
+            PT_MARK("interior_begin");
             {
                 if ((int32_t)cur > 0 && !special) {
                     if (STATS) (*nsteps)++;
@@ -564,6 +572,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     else popNext();
                 }
             }
+            PT_MARK("interior_end");
             // the rare lanes whose ray can produce NaN slab distances: the two-wide, NaN-rejecting step over the pair records
             if (__any((int32_t)cur > 0 && special)) {
                 if ((int32_t)cur > 0 && special) {
@@ -596,6 +605,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             if (nInterior != 0u && nLeaf < PT_LEAF_BATCH) break;
             if (refillable && 64u - nInterior - nLeaf >= refillMin) break;
             if (STATS) sched[1]++;
+            PT_MARK("leaf_begin");
             unsigned long long* const resKey = leafq;                       // [64] best (distance bits, triangle) per owner
             float2* const resUv = (float2*)(leafq + 64);                    // [64] its barycentrics
             uint32_t* const ownerOf = (uint32_t*)(leafq + 128);             // [64] owner lane of each dealt triangle
@@ -662,6 +672,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                 else if (leafJ == leafEnd) popNext();
             }
             __builtin_amdgcn_wave_barrier();
+            PT_MARK("leaf_end");
         }
     }
 }

@@ -63,12 +63,13 @@ def gather_accumulators(local, dst=0, group=None):
 class AccumulatorGather:
     """Once-per-image gather of one context's accumulator with preallocated buffers.
 
-    Each call waits for the context's own stream, snapshots the accumulator (a device copy on torch's
-    current stream) and gathers the snapshot.  With the "nccl" backend nothing blocks the host after the
-    snapshot is queued: RCCL reads the snapshot on its own stream while the caller already renders the next
-    image into the live accumulator, and the next call's snapshot is ordered after this gather by torch's
-    stream semantics.  `result` is the (world, n, 4) tensor on `dst` (None elsewhere); it is complete once
-    torch's current stream has caught up (torch.cuda.synchronize()).
+    Each call snapshots the accumulator and gathers the snapshot.  With the "nccl" backend nothing blocks the host: the
+    snapshot is a device copy queued on the context's OWN stream (after this image's kernels and before whatever the
+    caller enqueues next — the next pt_render or pt_reset_accumulation cannot overtake it), torch's current stream waits
+    for it through an event, and RCCL reads the snapshot while the context already renders the next image into the live
+    accumulator.  The next call's snapshot waits, again through an event, for this call's gather to have finished
+    reading the buffer.  `result` is the (world, n, 4) tensor on `dst` (None elsewhere); it is complete once torch's
+    current stream has caught up (torch.cuda.synchronize()).
     """
 
     def __init__(self, wf, dst=0, group=None):
@@ -84,13 +85,26 @@ class AccumulatorGather:
         self.result = None
         if self.rank == dst:
             self.result = torch.empty((self.world,) + tuple(self.local.shape), dtype=self.local.dtype, device=dev)
+        self._ctx_stream = torch.cuda.ExternalStream(wf.stream(), device=self.local.device) if self.on_device else None
+        self._gathered = None   # event: the previous gather has finished with the snapshot buffer
 
     def __call__(self):
+        import torch
         import torch.distributed as dist
-        self.wf.synchronize()
-        self.snapshot.copy_(self.local, non_blocking=self.on_device)
         parts = list(self.result.unbind(0)) if self.rank == self.dst else None
-        dist.gather(self.snapshot, parts, dst=self.dst, group=self.group)
+        if self.on_device:
+            mine, cur = self._ctx_stream, torch.cuda.current_stream()
+            if self._gathered is not None:
+                mine.wait_event(self._gathered)
+            with torch.cuda.stream(mine):
+                self.snapshot.copy_(self.local, non_blocking=True)
+            cur.wait_event(mine.record_event())
+            dist.gather(self.snapshot, parts, dst=self.dst, group=self.group)
+            self._gathered = cur.record_event()
+        else:
+            self.wf.synchronize()
+            self.snapshot.copy_(self.local)
+            dist.gather(self.snapshot, parts, dst=self.dst, group=self.group)
         return self.result
 
 

@@ -173,6 +173,12 @@ class Wavefront:
         self._check(self._lib.pt_accum_device(self._h, C.byref(p), C.byref(n), C.byref(s)))
         return p.value, n.value, s.value
 
+    def stream(self):
+        """The hipStream_t (as an integer) the context enqueues on."""
+        p = C.c_void_p()
+        self._check(self._lib.pt_stream(self._h, C.byref(p)))
+        return p.value or 0
+
     def assemble_tiles(self, gathered_device_ptr, world, samples):
         img = np.zeros((self.height, self.width, 4), np.float32)
         self._check(self._lib.pt_assemble_tiles(self._h, C.c_void_p(gathered_device_ptr), world, samples, _ptr(img)))

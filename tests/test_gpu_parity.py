@@ -946,6 +946,22 @@ assert res.is_cuda and tuple(res.shape[:1]) == (1,)
 img = wf.assemble_tiles(res.data_ptr(), 1, 2 * spp)
 want = wf.read_image()
 assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
+# the gathered image must be image k even when the caller overwrites the accumulator straight after gather():
+# a reset and a different frame are enqueued without any wait in between
+wf.reset_accumulation()
+wf.invoke(fs, spp=spp, max_bounces=4)
+want_a = wf.read_image()
+wf.reset_accumulation()
+wf.invoke(fs, spp=spp, max_bounces=4, wait=False)
+res = gather()
+wf.reset_accumulation()
+fs2 = Camera(w, h).frame_state((3, 4, 12), (0, 1, 0), frames=50, samples=0)
+for _ in range(4):
+    wf.invoke(fs2, spp=8, max_bounces=4, wait=False)
+torch.cuda.synchronize()
+wf.synchronize()
+img_a = wf.assemble_tiles(res.data_ptr(), 1, spp)
+assert np.array_equal(img_a.view(np.uint32), want_a.view(np.uint32)), "the gathered tiles hold samples of the next frame"
 t = torch.ones(4, device="cuda")
 dist.all_reduce(t)
 dist.barrier()

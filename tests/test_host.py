@@ -353,3 +353,12 @@ def test_two_rank_tile_gather_over_gloo(tmp_path):
                         "--master-port", "29613", str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "GLOO_TILES_OK" in r.stdout
+
+
+def test_isa_cost_file_is_current():
+    """pathtracer_amd/isa_cost.json (VALU instructions per traversal iteration, which bench.py prices the roofline with) must be
+    what tools/isa_cost.py derives from the kernels' assembly today."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_cost.py"), "--check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
