@@ -13,7 +13,9 @@ namespace PathTracer
         public struct Config
         {
             public int StructSize, Device, Nee, RngMode, TileRank, TileWorld, SamplesPerBatch, TraversalStats, StageTiming;
-            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 7)] public int[] Reserved;
+            public int DeviceCount;   // GPUs behind this one context (Device .. Device + DeviceCount - 1); tiles and the RCCL gather are internal
+            public int GroupFlags;
+            [MarshalAs(UnmanagedType.ByValArray, SizeConst = 5)] public int[] Reserved;
         }
 
         [DllImport(Lib)] public static extern int pt_default_config(ref Config cfg);

@@ -3,7 +3,10 @@
  *   libpt_host.so (pt_host.h)  Scene recipe, BVH build, camera   — stands in for the C# classes that a .NET host keeps
  *   libpt_hip.so  (pt_hip.h)   upload, render, read the image    — what replaces Wavefront.cs and the GL buffers
  *
- *   render_c <meshes.bin> <width> <height> <spp> <bounces> <out.raw|out.png|out.pfm> [gpu-build]
+ *   render_c <meshes.bin> <width> <height> <spp> <bounces> <out.raw|out.png|out.pfm> [gpu-build] [devices=N] [same-device] [force-rccl]
+ *
+ * devices=N renders on N GPUs through the same calls (pt_config.device_count): tiles are sharded and gathered inside the library,
+ * and the image is the same bits as on one GPU.  same-device puts all N members on GPU 0 (a rehearsal for machines with one GPU).
  *
  * Game.Initialize order (Game.cs:29-55): camera set at (0,2,15) -> (0,3,0) before the scene exists (focal distance 20),
  * InitializeScene(11), CopyToDevice, then frames with Frames = Samples = k.  Writes width*height float4 (or, for an output
@@ -21,7 +24,15 @@
 #define GPU(call) do { if ((call) != PT_OK) { fprintf(stderr, "%s: %s\n", #call, pt_last_error(ctx)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    if (argc < 7) { fprintf(stderr, "usage: %s meshes.bin width height spp bounces out.raw [gpu-build]\n", argv[0]); return 2; }
+    if (argc < 7) { fprintf(stderr, "usage: %s meshes.bin width height spp bounces out.raw [gpu-build] [devices=N] [same-device] [force-rccl]\n", argv[0]); return 2; }
+    int gpu_build = 0, devices = 1, flags = 0;
+    for (int a = 7; a < argc; a++) {
+        if (strcmp(argv[a], "gpu-build") == 0) gpu_build = 1;
+        else if (strncmp(argv[a], "devices=", 8) == 0) devices = atoi(argv[a] + 8);
+        else if (strcmp(argv[a], "same-device") == 0) flags |= PT_GROUP_SAME_DEVICE;
+        else if (strcmp(argv[a], "force-rccl") == 0) flags |= PT_GROUP_FORCE_RCCL;
+        else { fprintf(stderr, "unknown option %s\n", argv[a]); return 2; }
+    }
     const int width = atoi(argv[2]), height = atoi(argv[3]), spp = atoi(argv[4]), bounces = atoi(argv[5]);
 
     pth_scene* scene = pth_scene_create(argv[1]);
@@ -38,8 +49,10 @@ int main(int argc, char** argv) {
     pt_default_config(&cfg);
     cfg.nee = 1;
     cfg.rng_mode = 1;
+    cfg.device_count = devices;
+    cfg.group_flags = flags;
     GPU(pt_create(&cfg, &ctx));
-    if (argc > 7) {
+    if (gpu_build) {
         int32_t n_nodes = 0;
         GPU(pt_build_scene(ctx, materials, counts[0], triangles, counts[1], NULL, NULL, 0, &n_nodes, NULL));
     } else {
@@ -76,7 +89,7 @@ int main(int argc, char** argv) {
     }
     pt_stats st;
     GPU(pt_get_stats(ctx, &st));
-    printf("%dx%d %d spp: %llu extend rays, %llu shadow rays, checksum %016llx\n", width, height, spp, (unsigned long long)st.extend_rays,
+    printf("%dx%d %d spp on %d GPU context(s): %llu extend rays, %llu shadow rays, checksum %016llx\n", width, height, spp, devices, (unsigned long long)st.extend_rays,
            (unsigned long long)st.shadow_rays, (unsigned long long)h);
     free(image);
     pt_destroy(ctx);

@@ -11,6 +11,10 @@
  *   Node      32 B  PathTracer/Node.cs:5-10          (Bounds.Min@0 Bounds.Max@12 LeftFirst@24 Count@28)
  *   RenderState 32 B, FrameState 112 B               PathTracer/State.cs:20-41
  *
+ * One context can drive several GPUs of a node (pt_config.device_count): the host
+ * that replaces Wavefront.cs:40-56 gets them from the same create / render /
+ * read-image calls; tile sharding and the RCCL gather are inside the library.
+ *
  * All functions return PT_OK (0) or a negative pt_status; nothing throws across
  * the boundary.  pt_last_error() returns a message owned by the context (or by
  * the library when ctx is NULL).  A context is used by one thread at a time.
@@ -36,7 +40,8 @@ typedef enum pt_status {
     PT_E_OOM = -3,
     PT_E_HIP = -4,
     PT_E_BAD_BVH = -5,
-    PT_E_STATE = -6
+    PT_E_STATE = -6,
+    PT_E_RCCL = -7
 } pt_status;
 
 /* Constants the reference hard-codes, as fields (reference values are the defaults
@@ -53,8 +58,19 @@ typedef struct pt_config {
     int32_t traversal_stats;    /* 1 = count BVH steps / triangle tests (slower instrumented kernels) */
     int32_t stage_timing;       /* 1 = bracket every stage launch with events (pt_get_stats ms_*), 2 = the extend
                                    launches only (a pair of events costs about 5 us of stream time) */
-    int32_t reserved[7];
+    int32_t device_count;       /* GPUs behind this one context: devices device .. device + device_count - 1.  With more than one,
+                                   the scene is replicated, the image's 8x8 pixel groups are dealt round-robin to the GPUs, and
+                                   pt_read_image gathers the tiles to the first GPU with RCCL (grouped ncclSend / ncclRecv, once per
+                                   image); every other call keeps its meaning.  tile_rank / tile_world must then be 0 / 1. */
+    int32_t group_flags;        /* PT_GROUP_* */
+    int32_t reserved[5];
 } pt_config;
+
+/* pt_config.group_flags */
+enum { PT_GROUP_SAME_DEVICE = 1 /* rehearsal on a single GPU: all device_count members run on `device`; their tiles are gathered
+                                   by device-to-device copies, RCCL having one rank per GPU */,
+       PT_GROUP_FORCE_RCCL = 2  /* take the RCCL path even with device_count = 1 (a communicator of one rank that sends to
+                                   itself): exercises library loading, communicator set-up and the send/receive calls */ };
 
 typedef struct pt_stats {
     uint64_t paths;             /* primary rays generated */
@@ -105,7 +121,8 @@ int pt_reset_accumulation(pt_ctx* ctx);
 
 /* Replaces: frameState.CopyToDevice + Wavefront.Invoke, PathTracer/Game.cs:187-191, PathTracer/Wavefront.cs:40-56.
  * Traces `spp` samples; sample s uses frames = FrameState.Frames + s.  spp = 1, max_bounces = 10 is one
- * Wavefront.Invoke().  Work is enqueued on the context's stream; the call does not wait for it. */
+ * Wavefront.Invoke().  FrameState.Samples == 0 restarts the accumulation first (the reference's running mean,
+ * shade.glsl:89-96, forgets the old value when samples is 0); any other value adds to what is there.  Work is enqueued on the context's stream; the call does not wait for it. */
 int pt_render(pt_ctx* ctx, const void* frame_state112, int32_t spp, int32_t max_bounces);
 int pt_synchronize(pt_ctx* ctx);
 
@@ -166,7 +183,8 @@ enum { PT_OPT_NEE = 1, PT_OPT_RNG_MODE = 2, PT_OPT_TRAVERSAL_STATS = 3, PT_OPT_S
        PT_OPT_REFILL_BOUNCE = 8 /* the same for bounce and shadow rays; default 40 */ };
 int pt_set_option(pt_ctx* ctx, int32_t key, int32_t value);
 
-/* ---- multi-GPU tiles ---------------------------------------------------------
+/* ---- multi-GPU tiles, one process per GPU --------------------------------------
+ * (A single process reaches several GPUs through pt_config.device_count instead and needs none of this.)
  * Each rank accumulates only its own pixel groups.  pt_accum_device exposes the rank-local accumulator
  * (float4 per local slot, slots = local groups * 64, padded to the same length on every rank) so the caller can
  * gather it with RCCL; pt_assemble_tiles de-interleaves `world` gathered accumulators into a row-major image.

@@ -18,7 +18,8 @@ class NativeLibraryMissing(RuntimeError):
 class pt_config(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("nee", C.c_int32), ("rng_mode", C.c_int32),
                 ("tile_rank", C.c_int32), ("tile_world", C.c_int32), ("samples_per_batch", C.c_int32),
-                ("traversal_stats", C.c_int32), ("stage_timing", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("traversal_stats", C.c_int32), ("stage_timing", C.c_int32), ("device_count", C.c_int32), ("group_flags", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class pt_stats(C.Structure):

@@ -13,6 +13,12 @@
 #include <cmath>
 #include <algorithm>
 #include <mutex>
+#include <thread>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 namespace {
 
@@ -55,8 +61,11 @@ hipError_t resolveScratch(int device, void** out) {
 }
 }  // namespace
 
+struct Group;
+
 struct pt_ctx {
     pt_config cfg;
+    Group* group = nullptr;       // device_count > 1: this context only fans calls out to one member context per GPU
     std::string err;
     hipStream_t stream = nullptr;
     int num_cu = 256;
@@ -255,6 +264,121 @@ int guarded(pt_ctx* c, const char* what, F&& f) {
 }
 }  // namespace
 
+// ---- several GPUs behind one context ---------------------------------------------------------------------------
+// A context created with device_count > 1 owns one ordinary single-GPU context per device ("member", tile_rank = its
+// index): the scene is replicated, member i renders the pixel groups g with g % N == i, and pt_read_image gathers the
+// members' accumulators to member 0 once per image.  Every member has a host thread of its own, so blocking work
+// (uploads, builds, allocation) and the enqueueing of a frame's launches run on all GPUs at once.
+namespace {
+
+// RCCL, loaded when the first multi-GPU context is created: a single-GPU host never maps the library.
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) commInitAll = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclGroupStart) groupStart = nullptr;
+    decltype(&ncclGroupEnd) groupEnd = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGetErrorString) errorString = nullptr;
+    std::string problem;
+    bool load() {
+        if (handle) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) { problem = std::string("cannot load librccl: ") + dlerror(); return false; }
+        commInitAll = (decltype(commInitAll))dlsym(handle, "ncclCommInitAll");
+        commDestroy = (decltype(commDestroy))dlsym(handle, "ncclCommDestroy");
+        groupStart = (decltype(groupStart))dlsym(handle, "ncclGroupStart");
+        groupEnd = (decltype(groupEnd))dlsym(handle, "ncclGroupEnd");
+        send = (decltype(send))dlsym(handle, "ncclSend");
+        recv = (decltype(recv))dlsym(handle, "ncclRecv");
+        errorString = (decltype(errorString))dlsym(handle, "ncclGetErrorString");
+        if (!commInitAll || !commDestroy || !groupStart || !groupEnd || !send || !recv || !errorString) {
+            problem = "librccl lacks one of ncclCommInitAll/ncclCommDestroy/ncclGroupStart/ncclGroupEnd/ncclSend/ncclRecv/ncclGetErrorString";
+            handle = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+// One host thread that runs the jobs posted to it, one at a time.
+class Worker {
+public:
+    Worker() : th_([this] { loop(); }) {}
+    ~Worker() {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        th_.join();
+    }
+    void post(std::function<void()> job) {
+        { std::lock_guard<std::mutex> l(m_); job_ = std::move(job); pending_ = true; done_ = false; }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [this] { return done_; });
+    }
+private:
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return pending_ || stop_; });
+                if (!pending_ && stop_) return;
+                job = std::move(job_);
+                pending_ = false;
+            }
+            job();
+            { std::lock_guard<std::mutex> l(m_); done_ = true; }
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool pending_ = false, done_ = true, stop_ = false;
+    std::thread th_;
+};
+
+}  // namespace
+
+struct Group {
+    std::vector<pt_ctx*> members;
+    std::vector<std::unique_ptr<Worker>> workers;
+    std::vector<ncclComm_t> comms;        // one per member when the tiles travel by RCCL; empty: device-to-device copies
+    std::vector<hipEvent_t> ready;        // per member: its accumulator has been copied out (copy path)
+    float4* d_gather = nullptr;           // on member 0's GPU: N accumulators of slots_padded float4 each
+    size_t gather_slots = 0;
+
+    // Runs f(member) for every member on that member's thread and waits for all; the first failure is the result and
+    // its message becomes the owner's.  Nothing thrown by f leaves its thread.
+    template <class F>
+    int all(pt_ctx* owner, F f) {
+        std::vector<int> rc(members.size(), PT_OK);
+        for (size_t i = 0; i < members.size(); i++) {
+            pt_ctx* m = members[i];
+            int* out = &rc[i];
+            workers[i]->post([m, out, &f] { *out = guarded(m, "multi-GPU call", [&]() -> int { return f(m); }); });
+        }
+        for (auto& w : workers) w->wait();
+        for (size_t i = 0; i < members.size(); i++)
+            if (rc[i] != PT_OK) {
+                char b[640];
+                snprintf(b, sizeof(b), "device %d (member %zu of %zu): %s", members[i]->cfg.device, i, members.size(), members[i]->err.c_str());
+                owner->err = b;
+                return rc[i];
+            }
+        return PT_OK;
+    }
+};
+
 extern "C" {
 
 int pt_default_config(pt_config* cfg) {
@@ -262,14 +386,92 @@ int pt_default_config(pt_config* cfg) {
     memset(cfg, 0, sizeof(*cfg));
     cfg->struct_size = (int32_t)sizeof(pt_config);
     cfg->tile_world = 1;
+    cfg->device_count = 1;
     return PT_OK;
 }
 
 const char* pt_last_error(pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
+static void destroyGroup(pt_ctx* owner);
+static int impl_create_single(const pt_config* cfg, pt_ctx** out);
+
+// A context over several GPUs: one member context per device, a host thread each, and the communicators of the gather.
+static int impl_create_group(const pt_config* cfg, pt_ctx** out) {
+    const int n = cfg->device_count < 1 ? 1 : cfg->device_count;
+    const bool sameDevice = (cfg->group_flags & PT_GROUP_SAME_DEVICE) != 0;
+    if (cfg->tile_rank != 0 || cfg->tile_world != 1) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: device_count %d with tile rank %d of %d (a multi-GPU context shards by itself)", n, cfg->tile_rank, cfg->tile_world);
+    if (n > 64) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: device_count %d", n);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) FAIL((pt_ctx*)nullptr, PT_E_NO_DEVICE, "pt_create: no HIP device");
+    if (cfg->device < 0 || cfg->device + (sameDevice ? 1 : n) > ndev) FAIL((pt_ctx*)nullptr, PT_E_NO_DEVICE, "pt_create: devices %d..%d of %d", cfg->device, cfg->device + n - 1, ndev);
+    pt_ctx* owner = new pt_ctx();
+    owner->cfg = *cfg;
+    owner->group = new Group();
+    Group* g = owner->group;
+    for (int i = 0; i < n; i++) {
+        pt_config mc = *cfg;
+        mc.device = sameDevice ? cfg->device : cfg->device + i;
+        mc.device_count = 1;
+        mc.group_flags = 0;
+        mc.tile_rank = i;
+        mc.tile_world = n;
+        pt_ctx* m = nullptr;
+        const int rc = impl_create_single(&mc, &m);
+        if (rc != PT_OK) { destroyGroup(owner); return rc; }   // g_err holds the message
+        g->members.push_back(m);
+        g->workers.emplace_back(new Worker());
+    }
+    const bool rccl = (!sameDevice && n > 1) || (cfg->group_flags & PT_GROUP_FORCE_RCCL);
+    if (rccl) {
+        if (sameDevice && n > 1) { destroyGroup(owner); FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: RCCL needs one GPU per member; PT_GROUP_SAME_DEVICE and PT_GROUP_FORCE_RCCL only combine with device_count 1"); }
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        if (!g_rccl.load()) { destroyGroup(owner); FAIL((pt_ctx*)nullptr, PT_E_RCCL, "pt_create: %s", g_rccl.problem.c_str()); }
+        std::vector<int> devs;
+        for (pt_ctx* m : g->members) devs.push_back(m->cfg.device);
+        g->comms.assign(n, nullptr);
+        const ncclResult_t r = g_rccl.commInitAll(g->comms.data(), n, devs.data());
+        if (r != ncclSuccess) {
+            g->comms.clear();
+            destroyGroup(owner);
+            FAIL((pt_ctx*)nullptr, PT_E_RCCL, "pt_create: ncclCommInitAll over %d GPUs: %s", n, g_rccl.errorString(r));
+        }
+    } else {
+        for (pt_ctx* m : g->members) {
+            hipEvent_t e = nullptr;
+            if (hipSetDevice(m->cfg.device) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                destroyGroup(owner);
+                FAIL((pt_ctx*)nullptr, PT_E_HIP, "pt_create: no event for member on device %d", m->cfg.device);
+            }
+            g->ready.push_back(e);
+        }
+    }
+    *out = owner;
+    return PT_OK;
+}
+
+static void destroyGroup(pt_ctx* owner) {
+    Group* g = owner->group;
+    if (g) {
+        for (pt_ctx* m : g->members) { (void)hipSetDevice(m->cfg.device); if (m->stream) (void)hipStreamSynchronize(m->stream); }
+        for (ncclComm_t cm : g->comms) if (cm) (void)g_rccl.commDestroy(cm);
+        for (hipEvent_t e : g->ready) (void)hipEventDestroy(e);
+        if (g->d_gather && !g->members.empty()) { (void)hipSetDevice(g->members[0]->cfg.device); (void)hipFree(g->d_gather); }
+        g->workers.clear();   // joins the threads
+        for (pt_ctx* m : g->members) pt_destroy(m);
+        delete g;
+    }
+    delete owner;
+}
+
 static int impl_create(const pt_config* cfg, pt_ctx** out) {
     if (!cfg || !out) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: null argument");
     if (cfg->struct_size != (int32_t)sizeof(pt_config)) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: struct_size %d, expected %zu", cfg->struct_size, sizeof(pt_config));
+    if (cfg->device_count < 0) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: device_count %d", cfg->device_count);
+    if (cfg->device_count > 1 || (cfg->group_flags & PT_GROUP_FORCE_RCCL)) return impl_create_group(cfg, out);
+    return impl_create_single(cfg, out);
+}
+
+static int impl_create_single(const pt_config* cfg, pt_ctx** out) {
     if (cfg->tile_world < 1 || cfg->tile_rank < 0 || cfg->tile_rank >= cfg->tile_world) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: tile rank %d of %d", cfg->tile_rank, cfg->tile_world);
     if (cfg->nee < 0 || cfg->nee > 2) FAIL((pt_ctx*)nullptr, PT_E_INVALID_ARG, "pt_create: nee %d", cfg->nee);
     int ndev = 0;
@@ -310,6 +512,7 @@ static int impl_create(const pt_config* cfg, pt_ctx** out) {
 
 int pt_destroy(pt_ctx* c) {
     if (!c) return PT_OK;
+    if (c->group) { destroyGroup(c); return PT_OK; }
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     freeQueues(c);
@@ -326,6 +529,13 @@ int pt_destroy(pt_ctx* c) {
 
 int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
     if (!c) return PT_E_INVALID_ARG;
+    if (c->group) {
+        for (pt_ctx* m : c->group->members) {
+            const int rc = pt_set_option(m, key, value);
+            if (rc != PT_OK) { c->err = m->err; return rc; }
+        }
+        return PT_OK;
+    }
     switch (key) {
         case PT_OPT_NEE: if (value < 0 || value > 2) FAIL(c, PT_E_INVALID_ARG, "nee %d", value); c->cfg.nee = value; break;
         case PT_OPT_RNG_MODE: if (value != 0 && value != 1) FAIL(c, PT_E_INVALID_ARG, "rng_mode %d", value); c->cfg.rng_mode = value; break;
@@ -344,10 +554,23 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
     return PT_OK;
 }
 
-static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles, int32_t n_tri, const void* nodes, int32_t n_nodes) {
-    if (!c) return PT_E_INVALID_ARG;
+// The uploaded scene in the device layouts, still on the host: packed once, installed on one GPU or on several.
+struct QuadRecord { float box[6][4]; uint32_t entry[4]; uint32_t pad[4]; };
+static_assert(sizeof(QuadRecord) == 128, "quad record is one 128-byte line");
+struct PackedScene {
+    std::vector<HostNode> pairs;
+    std::vector<QuadRecord> quads;
+    std::vector<uint2> big;
+    std::vector<float4> hot, cold, lights;
+    const void* mats = nullptr;
+    int32_t n_mat = 0, n_tri = 0, n_nodes = 0;
+    float lightSum = 0.0f;
+    HostNode root{};
+};
+
+// Validates the host's arrays (nothing a kernel indexes with may be out of range) and repacks them; `c` only receives errors.
+static int packScene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles, int32_t n_tri, const void* nodes, int32_t n_nodes, PackedScene& out) {
     if (n_mat < 0 || n_tri < 0 || n_nodes < 0 || (n_mat && !materials) || (n_tri && !triangles) || (n_nodes && !nodes)) FAIL(c, PT_E_INVALID_ARG, "pt_upload_scene: bad counts or null arrays");
-    HIPCHECK(c, hipSetDevice(c->cfg.device));
     const HostNode* hn = (const HostNode*)nodes;
     const HostTriangle* ht = (const HostTriangle*)triangles;
     const HostMaterial* hm = (const HostMaterial*)materials;
@@ -360,12 +583,13 @@ static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, co
     for (int i = 0; i < n_tri; i++)
         if (ht[i].material < 0 || ht[i].material >= n_mat) FAIL(c, PT_E_INVALID_ARG, "triangle %d has material %d of %d", i, ht[i].material, n_mat);
 
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
-    freeScene(c);
-
-    // ---- repack
     const int n_pairs = n_nodes > 0 ? (n_nodes - 1) / 2 : 0;
-    std::vector<float4> hot((size_t)n_tri * 3), cold((size_t)n_tri * 3), lights;
+    out.mats = materials;
+    out.n_mat = n_mat; out.n_tri = n_tri; out.n_nodes = n_nodes;
+    if (n_nodes > 0) out.root = hn[0];
+    std::vector<float4>&hot = out.hot, &cold = out.cold, &lights = out.lights;
+    hot.resize((size_t)n_tri * 3);
+    cold.resize((size_t)n_tri * 3);
     float lightSum = 0.0f;
     for (int i = 0; i < n_tri; i++) {
         const HostTriangle& t = ht[i];
@@ -381,16 +605,12 @@ static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, co
         const HostMaterial& m = hm[t.material];
         if (m.emissive[0] > 0 || m.emissive[1] > 0 || m.emissive[2] > 0) appendLight(t, lights, lightSum);   // shade.glsl:366
     }
-    auto upload = [&](void** dst, const void* src, size_t bytes) -> int {
-        if (bytes == 0) { *dst = nullptr; return PT_OK; }
-        HIPCHECK(c, hipMalloc(dst, bytes));
-        HIPCHECK(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
-        return PT_OK;
-    };
+    out.lightSum = lightSum;
     // sibling pair k = nodes[2k+1], nodes[2k+2]: the node array shifted by one node lands on 64-byte lines;
     // each node's leftFirst word becomes its traversal entry
-    std::vector<HostNode> pairs(hn + (n_pairs ? 1 : 0), hn + (n_pairs ? 1 + 2 * (size_t)n_pairs : 0));
-    std::vector<uint2> big;
+    std::vector<HostNode>& pairs = out.pairs;
+    pairs.assign(hn + (n_pairs ? 1 : 0), hn + (n_pairs ? 1 + 2 * (size_t)n_pairs : 0));
+    std::vector<uint2>& big = out.big;
     std::vector<uint32_t> leafEntry(pairs.size() + 1, 0u);   // by node index
     for (size_t i = 0; i < pairs.size(); i++) {
         HostNode& nd = pairs[i];
@@ -402,9 +622,7 @@ static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, co
     }
     if (big.size() >= PT_LEAF_MAX_FIRST) FAIL(c, PT_E_BAD_BVH, "%zu leaves of more than %d triangles", big.size(), PT_LEAF_MAX_COUNT);
     // quad records: every other level of the tree, starting at the root
-    struct Quad { float box[6][4]; uint32_t entry[4]; uint32_t pad[4]; };
-    static_assert(sizeof(Quad) == 128, "quad record is one 128-byte line");
-    std::vector<Quad> quads;
+    std::vector<QuadRecord>& quads = out.quads;
     if (n_pairs > 0 && hn[0].count <= 0) {
         std::vector<std::pair<int32_t, uint32_t>> work;   // (interior node, its quad)
         quads.emplace_back();
@@ -419,7 +637,7 @@ static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, co
                 if (hn[ch].count > 0) kids[nk++] = ch;
                 else { kids[nk++] = hn[ch].leftFirst; kids[nk++] = hn[ch].leftFirst + 1; }
             }
-            Quad q{};
+            QuadRecord q{};
             for (int k = 0; k < nk; k++) {
                 const HostNode& kd = hn[kids[k]];
                 for (int a = 0; a < 3; a++) { q.box[a][k] = kd.mn[a]; q.box[3 + a][k] = kd.mx[a]; }
@@ -434,14 +652,28 @@ static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, co
         }
         if (quads.size() >= 0x7FFFFFFFu) FAIL(c, PT_E_BAD_BVH, "%zu quad records", quads.size());
     }
-    if ((rc = upload(&c->d_pairs, pairs.data(), pairs.size() * sizeof(HostNode))) != PT_OK) return rc;
-    if ((rc = upload(&c->d_quads, quads.data(), quads.size() * sizeof(Quad))) != PT_OK) return rc;
-    if ((rc = upload(&c->d_big, big.data(), big.size() * sizeof(uint2))) != PT_OK) return rc;
-    if ((rc = upload(&c->d_hot, hot.data(), hot.size() * sizeof(float4))) != PT_OK) return rc;
-    if ((rc = upload(&c->d_cold, cold.data(), cold.size() * sizeof(float4))) != PT_OK) return rc;
-    if ((rc = upload(&c->d_mats, hm, (size_t)n_mat * 48)) != PT_OK) return rc;
-    if ((rc = upload(&c->d_lights, lights.data(), lights.size() * sizeof(float4))) != PT_OK) return rc;
+    return PT_OK;
+}
 
+// Copies a packed scene to the context's GPU; the context's previous scene is released only once the new one is complete.
+static int installScene(pt_ctx* c, const PackedScene& p) {
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    void* fresh[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const void* src[7] = {p.pairs.data(), p.quads.data(), p.big.data(), p.hot.data(), p.cold.data(), p.mats, p.lights.data()};
+    const size_t bytes[7] = {p.pairs.size() * sizeof(HostNode), p.quads.size() * sizeof(QuadRecord), p.big.size() * sizeof(uint2), p.hot.size() * sizeof(float4),
+                             p.cold.size() * sizeof(float4), (size_t)p.n_mat * 48, p.lights.size() * sizeof(float4)};
+    for (int k = 0; k < 7; k++) {
+        if (bytes[k] == 0) continue;
+        hipError_t e = hipMalloc(&fresh[k], bytes[k]);
+        if (e == hipSuccess) e = hipMemcpy(fresh[k], src[k], bytes[k], hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            for (void* m : fresh) if (m) (void)hipFree(m);
+            FAIL(c, (e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "scene upload (%zu bytes): %s", bytes[k], hipGetErrorString(e));
+        }
+    }
+    freeScene(c);
+    c->d_pairs = fresh[0]; c->d_quads = fresh[1]; c->d_big = fresh[2]; c->d_hot = fresh[3]; c->d_cold = fresh[4]; c->d_mats = fresh[5]; c->d_lights = fresh[6];
     DevScene& sc = c->sc;
     sc.pairs = (const float4*)c->d_pairs;
     sc.quads = (const float4*)c->d_quads;
@@ -450,22 +682,44 @@ static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, co
     sc.tri_cold = (const float4*)c->d_cold;
     sc.mats = (const float4*)c->d_mats;
     sc.lights = (const float4*)c->d_lights;
-    sc.n_nodes = n_nodes;
-    sc.n_tris = n_tri;
-    sc.n_lights = (int32_t)(lights.size() / 3);
-    sc.light_total = lightSum;
-    if (n_nodes > 0) {
-        for (int k = 0; k < 3; k++) { sc.root_min[k] = hn[0].mn[k]; sc.root_max[k] = hn[0].mx[k]; }
-        sc.root_left = hn[0].leftFirst;
-        sc.root_count = hn[0].count;
+    sc.n_nodes = p.n_nodes;
+    sc.n_tris = p.n_tri;
+    sc.n_lights = (int32_t)(p.lights.size() / 3);
+    sc.light_total = p.lightSum;
+    if (p.n_nodes > 0) {
+        for (int k = 0; k < 3; k++) { sc.root_min[k] = p.root.mn[k]; sc.root_max[k] = p.root.mx[k]; }
+        sc.root_left = p.root.leftFirst;
+        sc.root_count = p.root.count;
     }
     c->has_scene = true;
     return PT_OK;
 }
 
+static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles, int32_t n_tri, const void* nodes, int32_t n_nodes) {
+    if (!c) return PT_E_INVALID_ARG;
+    PackedScene packed;
+    int rc = packScene(c, materials, n_mat, triangles, n_tri, nodes, n_nodes, packed);
+    if (rc != PT_OK) return rc;
+    if (c->group) return c->group->all(c, [&](pt_ctx* m) { return installScene(m, packed); });
+    return installScene(c, packed);
+}
+
 static int impl_resize(pt_ctx* c, int32_t width, int32_t height) {
     if (!c) return PT_E_INVALID_ARG;
     if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28)) FAIL(c, PT_E_INVALID_ARG, "pt_resize: %d x %d", width, height);
+    if (c->group) {
+        Group* g = c->group;
+        int rc = g->all(c, [&](pt_ctx* m) { return impl_resize(m, width, height); });
+        if (rc != PT_OK) return rc;
+        pt_ctx* first = g->members[0];
+        HIPCHECK(c, hipSetDevice(first->cfg.device));
+        if (g->d_gather) { (void)hipFree(g->d_gather); g->d_gather = nullptr; }
+        g->gather_slots = (size_t)std::max(1u, first->slots_padded);
+        HIPCHECK(c, hipMalloc((void**)&g->d_gather, g->gather_slots * g->members.size() * sizeof(float4)));
+        c->width = width;
+        c->height = height;
+        return PT_OK;
+    }
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     freeQueues(c);
@@ -493,6 +747,13 @@ static int impl_resize(pt_ctx* c, int32_t width, int32_t height) {
 
 int pt_set_render_state(pt_ctx* c, const void* rs32) {
     if (!c || !rs32) return PT_E_INVALID_ARG;
+    if (c->group) {
+        for (pt_ctx* m : c->group->members) {
+            const int rc = pt_set_render_state(m, rs32);
+            if (rc != PT_OK) { c->err = m->err; return rc; }
+        }
+        return PT_OK;
+    }
     HostRenderState rs;
     memcpy(&rs, rs32, sizeof(rs));
     if (rs.width != c->width || rs.height != c->height) FAIL(c, PT_E_INVALID_ARG, "render state is %d x %d, pt_resize was %d x %d", rs.width, rs.height, c->width, c->height);
@@ -503,6 +764,13 @@ int pt_set_render_state(pt_ctx* c, const void* rs32) {
 
 int pt_reset_accumulation(pt_ctx* c) {
     if (!c) return PT_E_INVALID_ARG;
+    if (c->group) {
+        for (pt_ctx* m : c->group->members) {
+            const int rc = pt_reset_accumulation(m);
+            if (rc != PT_OK) { c->err = m->err; return rc; }
+        }
+        return PT_OK;
+    }
     if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_reset_accumulation before pt_resize");
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HIPCHECK(c, hipMemsetAsync(c->d_sum, 0, (size_t)std::max(1u, c->slots_padded) * sizeof(float4), c->stream));
@@ -593,6 +861,8 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
 
 static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32_t max_bounces) {
     if (!c || !frame_state112) return PT_E_INVALID_ARG;
+    // every member enqueues its own tiles' launches from its own host thread
+    if (c->group) return c->group->all(c, [&](pt_ctx* m) { return impl_render(m, frame_state112, spp, max_bounces); });
     if (spp < 1 || max_bounces < 1 || max_bounces > 64) FAIL(c, PT_E_INVALID_ARG, "pt_render: spp %d, max_bounces %d", spp, max_bounces);
     if (!c->has_scene) FAIL(c, PT_E_STATE, "pt_render before pt_upload_scene");
     if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_render before pt_resize");
@@ -600,6 +870,12 @@ static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HostFrameState fs;
     memcpy(&fs, frame_state112, sizeof(fs));
+    // FrameState.Samples == 0 is how the host restarts the picture (Game.cs:140,157-165): the running mean of
+    // shade.glsl:89-96 then discards the old value, so the accumulator starts over here too
+    if (fs.samples == 0 && c->samples_accumulated != 0) {
+        HIPCHECK(c, hipMemsetAsync(c->d_sum, 0, (size_t)std::max(1u, c->slots_padded) * sizeof(float4), c->stream));
+        c->samples_accumulated = 0;
+    }
     HIPCHECK(c, hipEventRecord(c->ev_begin, c->stream));
     int rc = renderBatches(c, fs, spp, max_bounces, false);
     if (rc != PT_OK) return rc;
@@ -611,6 +887,13 @@ static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32
 
 int pt_synchronize(pt_ctx* c) {
     if (!c) return PT_E_INVALID_ARG;
+    if (c->group) {
+        for (pt_ctx* m : c->group->members) {
+            const int rc = pt_synchronize(m);
+            if (rc != PT_OK) { c->err = m->err; return rc; }
+        }
+        return PT_OK;
+    }
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     if (c->render_pending) {
@@ -624,12 +907,14 @@ int pt_synchronize(pt_ctx* c) {
 
 int pt_stream(pt_ctx* c, void** stream) {
     if (!c || !stream) return PT_E_INVALID_ARG;
+    if (c->group) FAIL(c, PT_E_STATE, "pt_stream on a multi-GPU context: it has one stream per GPU and orders them itself");
     *stream = (void*)c->stream;
     return PT_OK;
 }
 
 int pt_accum_device(pt_ctx* c, void** device_ptr, uint64_t* n_slots_padded, uint32_t* samples) {
     if (!c) return PT_E_INVALID_ARG;
+    if (c->group) FAIL(c, PT_E_STATE, "pt_accum_device on a multi-GPU context: pt_read_image gathers the tiles itself");
     if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_accum_device before pt_resize");
     if (device_ptr) *device_ptr = c->d_sum;
     if (n_slots_padded) *n_slots_padded = c->slots_padded;
@@ -639,6 +924,7 @@ int pt_accum_device(pt_ctx* c, void** device_ptr, uint64_t* n_slots_padded, uint
 
 static int impl_assemble_tiles(pt_ctx* c, const void* gathered_device, int32_t world, uint32_t samples, float* rgba_host) {
     if (!c || !gathered_device || !rgba_host) return PT_E_INVALID_ARG;
+    if (c->group) FAIL(c, PT_E_STATE, "pt_assemble_tiles on a multi-GPU context: pt_read_image gathers the tiles itself");
     if (world != c->cfg.tile_world) FAIL(c, PT_E_INVALID_ARG, "pt_assemble_tiles: world %d, context was created for %d", world, c->cfg.tile_world);
     if (!c->d_image) FAIL(c, PT_E_STATE, "pt_assemble_tiles before pt_resize");
     HIPCHECK(c, hipSetDevice(c->cfg.device));
@@ -649,8 +935,44 @@ static int impl_assemble_tiles(pt_ctx* c, const void* gathered_device, int32_t w
     return pt_synchronize(c);
 }
 
+// The once-per-image exchange of a multi-GPU context: every member's accumulator (slots_padded float4) to member 0's GPU,
+// then the de-interleave there.  RCCL: one grouped ncclSend per member on its own stream (so it follows that member's
+// kernels) and the matching ncclRecv on member 0's stream — a direct gather over the point-to-point xGMI links, no ring.
+static int groupReadImage(pt_ctx* c, float* rgba) {
+    Group* g = c->group;
+    pt_ctx* first = g->members[0];
+    if (!g->d_gather) FAIL(c, PT_E_STATE, "pt_read_image before pt_resize");
+    const size_t n = g->members.size(), stride = g->gather_slots, bytes = stride * sizeof(float4);
+    HIPCHECK(c, hipSetDevice(first->cfg.device));
+    if (!g->comms.empty()) {
+        ncclResult_t r = g_rccl.groupStart();
+        for (size_t i = 0; i < n && r == ncclSuccess; i++) {
+            if (i == 0 && n > 1) continue;   // member 0's own tiles are a local copy (below); a lone member sends to itself
+            r = g_rccl.send(g->members[i]->d_sum, stride * 4, ncclFloat, 0, g->comms[i], g->members[i]->stream);
+            if (r == ncclSuccess) r = g_rccl.recv(g->d_gather + i * stride, stride * 4, ncclFloat, (int)i, g->comms[0], first->stream);
+        }
+        const ncclResult_t e = g_rccl.groupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) FAIL(c, PT_E_RCCL, "tile gather: %s", g_rccl.errorString(r));
+        if (n > 1) HIPCHECK(c, hipMemcpyAsync(g->d_gather, first->d_sum, bytes, hipMemcpyDeviceToDevice, first->stream));
+    } else {
+        for (size_t i = 0; i < n; i++) {
+            pt_ctx* m = g->members[i];
+            HIPCHECK(c, hipMemcpyAsync(g->d_gather + i * stride, m->d_sum, bytes, hipMemcpyDeviceToDevice, m->stream));
+            if (i > 0) {
+                HIPCHECK(c, hipEventRecord(g->ready[i], m->stream));
+                HIPCHECK(c, hipStreamWaitEvent(first->stream, g->ready[i], 0));
+            }
+        }
+    }
+    const int rc = impl_assemble_tiles(first, g->d_gather, (int32_t)n, std::max(1u, first->samples_accumulated), rgba);
+    if (rc != PT_OK) { c->err = first->err; return rc; }
+    return pt_synchronize(c);
+}
+
 static int impl_read_image(pt_ctx* c, float* rgba) {
     if (!c || !rgba) return PT_E_INVALID_ARG;
+    if (c->group) return groupReadImage(c, rgba);
     if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_read_image before pt_resize");
     if (c->cfg.tile_world != 1) FAIL(c, PT_E_STATE, "pt_read_image on a tile-sharded context: gather with pt_accum_device + pt_assemble_tiles");
     return pt_assemble_tiles(c, c->d_sum, 1, std::max(1u, c->samples_accumulated), rgba);
@@ -658,6 +980,12 @@ static int impl_read_image(pt_ctx* c, float* rgba) {
 
 static int traceCommon(pt_ctx* c, bool anyhit, const float* o_d, const float* tmax, int32_t n, int32_t* tri, float* t, float* uv, uint8_t* occ) {
     if (!c || n < 0 || (n && !o_d)) return PT_E_INVALID_ARG;
+    if (c->group) {   // single queries run on the first GPU
+        pt_ctx* m = c->group->members[0];
+        const int rc = traceCommon(m, anyhit, o_d, tmax, n, tri, t, uv, occ);
+        if (rc != PT_OK) c->err = m->err;
+        return rc;
+    }
     if (!c->has_scene) FAIL(c, PT_E_STATE, "trace before pt_upload_scene");
     if (n == 0) return PT_OK;
     HIPCHECK(c, hipSetDevice(c->cfg.device));
@@ -710,6 +1038,12 @@ static int impl_trace_occluded(pt_ctx* c, const float* o_d, const float* tmax, i
 // overwritten by the next.  Calls that overlap on one GPU share the array and race.
 int pt_trace_closest_noalloc(pt_ctx* c, const float* o_d, int32_t n, int32_t* tri, float* t, float* uv) {
     if (!c || n < 0 || (n && !o_d)) return PT_E_INVALID_ARG;
+    if (c->group) {
+        pt_ctx* m = c->group->members[0];
+        const int rc = pt_trace_closest_noalloc(m, o_d, n, tri, t, uv);
+        if (rc != PT_OK) c->err = m->err;
+        return rc;
+    }
     if (n > PT_NOALLOC_MAX_RAYS) FAIL(c, PT_E_INVALID_ARG, "pt_trace_closest_noalloc: %d rays, the fixed staging array holds at most %d per call", n, PT_NOALLOC_MAX_RAYS);
     if (!c->has_scene) FAIL(c, PT_E_STATE, "trace before pt_upload_scene");
     if (!c->scratch_dev) FAIL(c, PT_E_STATE, "pt_trace_closest_noalloc: the staging array was not resolved on device %d", c->cfg.device);
@@ -734,6 +1068,7 @@ int pt_trace_closest_noalloc(pt_ctx* c, const float* o_d, int32_t n, int32_t* tr
 
 static int impl_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, float* o_d, uint32_t* pixel) {
     if (!c || !frame_state112 || !o_d || !pixel || n < 0) return PT_E_INVALID_ARG;
+    if (c->group) FAIL(c, PT_E_STATE, "pt_generate_rays on a multi-GPU context: thread indices are per GPU; use a single-GPU context");
     if (!c->d_sum) FAIL(c, PT_E_STATE, "pt_generate_rays before pt_resize");
     if (!c->has_rs) FAIL(c, PT_E_STATE, "pt_generate_rays before pt_set_render_state");
     if ((uint32_t)n > c->slots) FAIL(c, PT_E_INVALID_ARG, "pt_generate_rays: n %d > local slots %u", n, c->slots);
@@ -769,6 +1104,12 @@ static int impl_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, 
 
 static int impl_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t iters, float* avg_ms, int32_t* tri, float* t) {
     if (!c || !o_d || n <= 0 || iters <= 0 || !avg_ms) return PT_E_INVALID_ARG;
+    if (c->group) {
+        pt_ctx* m = c->group->members[0];
+        const int rc = impl_bench_extend(m, o_d, n, iters, avg_ms, tri, t);
+        if (rc != PT_OK) c->err = m->err;
+        return rc;
+    }
     if (!c->has_scene) FAIL(c, PT_E_STATE, "pt_bench_extend before pt_upload_scene");
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
@@ -813,6 +1154,12 @@ static int impl_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t ite
 static int impl_build_bvh(pt_ctx* c, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out, int32_t node_capacity, int32_t* n_nodes,
                  float* build_ms) {
     if (!c || n_tri < 0 || (n_tri && (!triangles_in || !triangles_out)) || !nodes_out || !n_nodes) return PT_E_INVALID_ARG;
+    if (c->group) {
+        pt_ctx* m = c->group->members[0];
+        const int rc = impl_build_bvh(m, triangles_in, n_tri, triangles_out, nodes_out, node_capacity, n_nodes, build_ms);
+        if (rc != PT_OK) c->err = m->err;
+        return rc;
+    }
     const int32_t need = n_tri ? 2 * n_tri - 1 : 1;
     if (node_capacity < need) FAIL(c, PT_E_INVALID_ARG, "pt_build_bvh: room for %d nodes, %d triangles may need %d", node_capacity, n_tri, need);
     HIPCHECK(c, hipSetDevice(c->cfg.device));
@@ -849,6 +1196,15 @@ static int impl_build_bvh(pt_ctx* c, const void* triangles_in, int32_t n_tri, vo
 static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out,
                    int32_t node_capacity, int32_t* n_nodes, float* build_ms) {
     if (!c || n_mat < 0 || n_tri < 0 || (n_mat && !materials) || (n_tri && !triangles_in)) return PT_E_INVALID_ARG;
+    if (c->group) {
+        // every GPU builds its own replica (the build is deterministic: the trees are identical); the first hands the arrays back
+        pt_ctx* first = c->group->members[0];
+        return c->group->all(c, [&](pt_ctx* m) {
+            const bool lead = m == first;
+            return impl_build_scene(m, materials, n_mat, triangles_in, n_tri, lead ? triangles_out : nullptr, lead ? nodes_out : nullptr, node_capacity,
+                                    lead ? n_nodes : nullptr, lead ? build_ms : nullptr);
+        });
+    }
     const int32_t need = n_tri ? 2 * n_tri - 1 : 1;
     if (nodes_out && node_capacity < need) FAIL(c, PT_E_INVALID_ARG, "pt_build_scene: room for %d nodes, %d triangles may need %d", node_capacity, n_tri, need);
     HIPCHECK(c, hipSetDevice(c->cfg.device));
@@ -987,6 +1343,25 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
 
 int pt_get_stats(pt_ctx* c, pt_stats* out) {
     if (!c || !out) return PT_E_INVALID_ARG;
+    if (c->group) {
+        // ray and step counts add up over the GPUs; times are the slowest GPU's; launch counts are per GPU
+        pt_stats total{};
+        for (size_t i = 0; i < c->group->members.size(); i++) {
+            pt_stats s;
+            const int rc = pt_get_stats(c->group->members[i], &s);
+            if (rc != PT_OK) { c->err = c->group->members[i]->err; return rc; }
+            if (i == 0) { total = s; continue; }
+            total.paths += s.paths; total.extend_rays += s.extend_rays; total.shadow_rays += s.shadow_rays;
+            total.extend_steps += s.extend_steps; total.extend_tris += s.extend_tris; total.shadow_steps += s.shadow_steps; total.shadow_tris += s.shadow_tris;
+            total.stack_overflows += s.stack_overflows; total.sched_interior += s.sched_interior; total.sched_leaf += s.sched_leaf;
+            total.sched_refill += s.sched_refill; total.special_rays += s.special_rays;
+            total.ms_generate = std::max(total.ms_generate, s.ms_generate); total.ms_extend = std::max(total.ms_extend, s.ms_extend);
+            total.ms_shade = std::max(total.ms_shade, s.ms_shade); total.ms_connect = std::max(total.ms_connect, s.ms_connect);
+            total.ms_render = std::max(total.ms_render, s.ms_render); total.ms_extend_primary = std::max(total.ms_extend_primary, s.ms_extend_primary);
+        }
+        *out = total;
+        return PT_OK;
+    }
     int rc = pt_synchronize(c);
     if (rc != PT_OK) return rc;
     Ctl ctl;
@@ -1010,6 +1385,13 @@ int pt_get_stats(pt_ctx* c, pt_stats* out) {
 
 int pt_reset_stats(pt_ctx* c) {
     if (!c) return PT_E_INVALID_ARG;
+    if (c->group) {
+        for (pt_ctx* m : c->group->members) {
+            const int rc = pt_reset_stats(m);
+            if (rc != PT_OK) { c->err = m->err; return rc; }
+        }
+        return PT_OK;
+    }
     int rc = pt_synchronize(c);
     if (rc != PT_OK) return rc;
     HIPCHECK(c, hipMemset(c->d_ctl, 0, sizeof(Ctl)));

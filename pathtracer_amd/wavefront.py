@@ -25,13 +25,14 @@ class Wavefront:
     """One rendering context on one GPU (pt_ctx)."""
 
     def __init__(self, device=0, nee=False, rng_mode=0, tile_rank=0, tile_world=1, samples_per_batch=0,
-                 traversal_stats=False, stage_timing=False):
+                 traversal_stats=False, stage_timing=False, device_count=1, group_flags=0):
         self._lib = _native.hip()
         cfg = _native.pt_config()
         self._check(self._lib.pt_default_config(C.byref(cfg)), None)
         cfg.device, cfg.nee, cfg.rng_mode = device, int(nee), rng_mode
         cfg.tile_rank, cfg.tile_world, cfg.samples_per_batch = tile_rank, tile_world, samples_per_batch
         cfg.traversal_stats, cfg.stage_timing = int(traversal_stats), int(stage_timing)
+        cfg.device_count, cfg.group_flags = device_count, group_flags
         self.tile_rank, self.tile_world = tile_rank, tile_world
         h = C.c_void_p()
         self._h = None

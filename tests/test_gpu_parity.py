@@ -774,6 +774,76 @@ def test_plain_c_host_renders_the_same_image(pa, bundled, tmp_path):
             assert np.isfinite(got).all() and abs(float(got[..., :3].mean()) / float(want[..., :3].mean()) - 1.0) < 0.03, r.stdout
 
 
+def test_one_context_over_several_gpus(pa, ob, bundled, tmp_path):
+    """pt_config.device_count: one context, the same calls, N member contexts inside the library.  Rehearsed on the one GPU
+    there is (PT_GROUP_SAME_DEVICE: three members on device 0, tiles gathered by device copies) — the image, the ray counts
+    and the traversal counters equal a single-GPU context's bit for bit, through ctypes and through the plain-C host; a
+    ragged image (77 groups over 3 members), the GPU-built scene and a second accumulation are covered too.  The RCCL path
+    itself (library loading, communicator, grouped ncclSend / ncclRecv on the members' streams) runs with the one rank a
+    single GPU allows (PT_GROUP_FORCE_RCCL)."""
+    import subprocess
+    from conftest import MESHES, ROOT
+    mats, tris, nodes = bundled.arrays()
+    for (w, h) in [(160, 96), (88, 56)]:
+        fs = bundled_view(bundled, w, h, frames=1)
+        fs["samples"] = 0
+        imgs, stats = {}, {}
+        for name, kw in [("one", {}), ("three", dict(device_count=3, group_flags=1)), ("rccl", dict(device_count=1, group_flags=2))]:
+            wf = pa.Wavefront(nee=True, rng_mode=1, traversal_stats=True, **kw)
+            wf.upload_scene(mats, tris, nodes)
+            wf.allocate(w, h)
+            f = fs.copy()
+            for spp in (2, 3):                      # two calls: accumulation carries over inside every member
+                wf.invoke(f, spp=spp, max_bounces=4)
+                f["frames"] += spp
+                f["samples"] += spp
+            imgs[name] = wf.read_image()
+            st = wf.stats()
+            stats[name] = tuple(st[k] for k in ("paths", "extend_rays", "shadow_rays", "extend_steps", "extend_tris", "shadow_steps", "shadow_tris"))
+            assert st["stack_overflows"] == 0
+            if name == "three":
+                rays = np.array([[0, 2, 15, 0.01, 0.05, -1.0]], np.float32)
+                assert wf.trace_closest(rays)["tri"][0] >= 0
+                with pytest.raises(pa.PtError):
+                    wf.accum_device()
+                wf.invoke(fs, spp=2, max_bounces=4)     # FrameState.Samples == 0: the accumulation restarts by itself
+                again = wf.read_image()
+            wf.close()
+        assert np.array_equal(bits(imgs["three"]), bits(imgs["one"])) and np.array_equal(bits(imgs["rccl"]), bits(imgs["one"]))
+        assert stats["three"] == stats["one"] == stats["rccl"]
+        ref = pa.Wavefront(nee=True, rng_mode=1)
+        ref.upload_scene(mats, tris, nodes)
+        ref.allocate(w, h)
+        ref.invoke(fs, spp=2, max_bounces=4)
+        assert np.array_equal(bits(again), bits(ref.read_image()))
+        ref.close()
+    # GPU build on every member
+    from pathtracer_amd.host import Scene
+    s = Scene()
+    s.initialize_scene(11)
+    hm, refs = s.references()
+    got = []
+    for kw in ({}, dict(device_count=2, group_flags=1)):
+        wf = pa.Wavefront(nee=True, rng_mode=1, **kw)
+        wf.build_scene(hm, refs)
+        wf.allocate(96, 64)
+        wf.invoke(bundled_view(bundled, 96, 64, frames=1), spp=2, max_bounces=4)
+        got.append(wf.read_image())
+        wf.close()
+    assert np.array_equal(bits(got[0]), bits(got[1]))
+    # the plain-C host with devices=3
+    exe = os.path.join(ROOT, "examples", "render_c")
+    outs = []
+    for extra in ([], ["devices=3", "same-device"], ["force-rccl"]):
+        out = tmp_path / "img.raw"
+        r = subprocess.run([exe, MESHES, "160", "96", "3", "4", str(out)] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.fromfile(out, np.float32))
+    assert np.array_equal(bits(outs[0]), bits(outs[1])) and np.array_equal(bits(outs[0]), bits(outs[2]))
+    with pytest.raises(pa.PtError):
+        pa.Wavefront(device_count=2)            # two distinct GPUs asked for, one present
+
+
 def test_command_line_renderer(pa, bundled, tmp_path):
     """python -m pathtracer_amd: the float image it writes equals a render through the API; the GPU-built variant (another
     valid tree over the same triangles) gives the same picture up to its light order; the PNG is well formed."""
