@@ -42,7 +42,11 @@ WORKLOADS = {
     "c5": ("4,026 instanced bunnies flattened (20.0M triangles), 3840x2160, 1024 spp in steps of 8, 8 bounces, NEE", 3840, 2160, 8, 8, 1),
 }
 
-# Vector-ALU peak the traversal kernels are priced against: one wave64 instruction per SIMD every 4 clocks, i.e. 16 lanes per
+# The roof that binds the traversal kernels (tools/micro/ta_rate.hip, profiles/r02_micro_ta_rate.txt): a CU's vector memory
+# pipeline returns about one lane's 16-byte load per clock, however the addresses fall (random lines, one line per lane, or fully
+# contiguous); only lanes of one instruction that ask for the SAME 16 bytes are served together.  256 CUs x 16 B x 2.4 GHz.
+VMEM_PEAK_GBS = 256 * 16 * 2.4e9 / 1e9
+# Vector-ALU peak, second entry: one wave64 instruction per SIMD every 4 clocks, i.e. 16 lanes per
 # SIMD and clock, 4 SIMDs x 256 CUs at 2.4 GHz.  Not the 157 TFLOP/s headline: that counts packed two-wide FMAs, and this path
 # may neither fuse (bit-exactness with the C# arithmetic) nor pack (one ray per lane).
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
@@ -206,18 +210,27 @@ class Run:
 
 
 def traversal_roofline(counted, timed, kernel_cost, n_quads, n_tris, pmc):
-    """The extend kernel against the vector-ALU issue roof, from counts of the instrumented pass and HIP-event times of the timed
-    steps.  Useful lane-operations = BVH steps x VALU instructions of one interior iteration + triangle tests x VALU instructions of
-    one leaf phase: what the walk needs if every lane of every issued instruction did useful work."""
+    """The extend kernel against the roof that binds it — the vector memory pipeline's return rate — from counts of the
+    instrumented pass and HIP-event times of the timed steps.
+
+    Algorithmic bytes per launch = 16 B x the DISTINCT 16-byte loads the walk needs: 7 per quad record a wave instruction fetches
+    (four boxes + four entries = 112 bytes), 3 per triangle record (48 bytes), 2 per ray (origin, direction); lanes of one wave
+    instruction that fetch the same record count once (the instrumented kernel counts distinct records per instruction).
+    Second and third entries: vector-ALU issue (useful lane-operations from the ISA's instruction counts) and HBM."""
     i_int, i_leaf = kernel_cost["interior_iteration"]["valu"], kernel_cost["leaf_phase"]["valu"]
     rays = max(1, counted["extend_rays"])
     steps_per_ray = counted["extend_steps"] / rays
     tris_per_ray = counted["extend_tris"] / rays
+    usteps_per_ray = counted["extend_unique_steps"] / rays
+    utris_per_ray = counted["extend_unique_tris"] / rays
     launches = max(1, timed["extend_launches"])
     avg_ms = timed["ms_extend"] / launches
+    sec = max(1e-12, avg_ms * 1e-3)
     rays_per_launch = timed["extend_rays"] / launches
+    loads_per_ray = 7.0 * usteps_per_ray + 3.0 * utris_per_ray + 2.0
+    vmem_achieved = 16.0 * loads_per_ray * rays_per_launch / sec / 1e9
     laneops_per_ray = steps_per_ray * i_int + tris_per_ray * i_leaf
-    achieved = laneops_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    valu_achieved = laneops_per_ray * rays_per_launch / sec / 1e12
     lane_int = counted["extend_steps"] / max(1, 64 * counted["sched_interior"])
     lane_leaf = counted["extend_tris"] / max(1, 64 * counted["sched_leaf"])
     issued = counted["sched_interior"] * i_int + counted["sched_leaf"] * i_leaf     # wave instructions, the two loops only
@@ -225,28 +238,36 @@ def traversal_roofline(counted, timed, kernel_cost, n_quads, n_tris, pmc):
     # triangle records; everything else the walk touches is re-use that the caches serve
     scene_bytes = 128.0 * n_quads + 48.0 * n_tris
     hbm_alg = 48.0 * rays_per_launch + scene_bytes
-    hbm_achieved = hbm_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    gathered = 128.0 * steps_per_ray + 48.0 * tris_per_ray
-    return {
-        "bound": "valu", "kernel": "k_extend", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
-        "frac": achieved / VALU_PEAK_TLANEOPS,
+    hbm_achieved = hbm_alg / sec / 1e9
+    vmem = {"bound": "vmem", "bound_note": "vector memory pipeline: one lane's 16-byte load returned per clock and CU (tools/micro/ta_rate.hip, "
+                                           "profiles/r02_micro_ta_rate.txt); binds incoherent rays",
+            "achieved": vmem_achieved, "peak": VMEM_PEAK_GBS, "unit": "GB/s", "frac": vmem_achieved / VMEM_PEAK_GBS,
+            "bytes_per_launch": 16.0 * loads_per_ray * rays_per_launch, "distinct_16B_loads_per_ray": loads_per_ray,
+            "distinct_bvh_records_per_ray": usteps_per_ray, "distinct_tri_records_per_ray": utris_per_ray,
+            "measured_ceilings_gbs": {"source": "profiles/r02_micro_ta_rate.txt", "contiguous": 9700.0, "own_128B_record_L2_resident": 8500.0,
+                                      "own_128B_record_infinity_cache_resident": 6880.0}}
+    valu = {"bound": "valu", "bound_note": "vector-ALU issue: one wave64 instruction per SIMD every 4 clocks, unfused and unpacked (bit-exactness with the C# "
+                                           "arithmetic forbids FMA contraction); binds coherent rays, whose loads the pipeline serves together",
+            "achieved": valu_achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": valu_achieved / VALU_PEAK_TLANEOPS,
+            "valu_instr_per_interior_iteration": i_int, "valu_instr_per_leaf_phase": i_leaf, "lane_ops_per_ray": laneops_per_ray,
+            "lane_utilisation": {"interior": lane_int, "leaf": lane_leaf,
+                                 "overall": (counted["extend_steps"] * i_int + counted["extend_tris"] * i_leaf) / max(1, 64 * issued)},
+            "issue_model_wave_instr_per_ray": issued / rays, "valu_busy_pmc": pmc.get("valu_busy")}
+    hbm = {"bound": "hbm", "bound_note": "ray records in and out plus one pass over the tree and the hot triangle records per launch; the walk's re-use is served by L2 / Infinity Cache",
+           "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "bytes_per_launch": hbm_alg, "scene_bytes": scene_bytes}
+    # the roof that binds is the one the kernel sits closest to; the other two stay in the line
+    first, second = (vmem, valu) if vmem["frac"] >= valu["frac"] else (valu, vmem)
+    out = dict(first)
+    out.update({
+        "kernel": "k_extend",
         "traffic": pmc.get("extend_hbm_bytes_per_launch"),
         "traffic_source": (pmc.get("source", "profiles/traffic.json") + " (committed PMC passes, not measured by this run)") if pmc else None,
         "launches": launches, "avg_launch_ms": avg_ms, "rays_per_launch": rays_per_launch,
-        "valu_instr_per_interior_iteration": i_int, "valu_instr_per_leaf_phase": i_leaf,
-        "bvh_steps_per_ray": steps_per_ray, "tri_tests_per_ray": tris_per_ray, "lane_ops_per_ray": laneops_per_ray,
-        "lane_utilisation": {"interior": lane_int, "leaf": lane_leaf,
-                             "overall": (counted["extend_steps"] * i_int + counted["extend_tris"] * i_leaf) / max(1, 64 * issued)},
-        "issue_model_wave_instr_per_ray": issued / rays,
-        "valu_busy_pmc": pmc.get("valu_busy"),
+        "bvh_steps_per_ray": steps_per_ray, "tri_tests_per_ray": tris_per_ray,
         "extend_mrays_per_s": timed["extend_rays"] / max(1e-9, timed["ms_extend"] * 1e-3) / 1e6,
-        # second roof, for the record: HBM.  achieved = the bytes a launch must move (ray records + one pass over the scene) / time;
-        # "gathered" is what the walk reads through the caches (the figure that exceeds the HBM peak: the tree lives in L2)
-        "hbm": {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
-                "bytes_per_launch": hbm_alg, "scene_bytes": scene_bytes,
-                "cache_served_bytes_per_ray": gathered,
-                "cache_served_gbs": gathered * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0},
-    }
+        "other_roofs": {second["bound"]: second, "hbm": hbm},
+    })
+    return out
 
 
 def timed_steps(run, steps, warmup, sync_all):
@@ -286,8 +307,8 @@ def secondary_soup(args, cost, steps=3):
         "rays_per_frame": {"extend": st["extend_rays"] / steps, "bounce": bounce_rays / steps, "shadow": st["shadow_rays"] / steps},
         "shadow_bvh_steps_per_ray": counted["shadow_steps"] / max(1, counted["shadow_rays"]),
         "shadow_tri_tests_per_ray": counted["shadow_tris"] / max(1, counted["shadow_rays"]),
-        "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "bvh_steps_per_ray",
-                                           "tri_tests_per_ray", "lane_utilisation")},
+        "roofline": {**{k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "bvh_steps_per_ray", "tri_tests_per_ray")},
+                     "other_roofs": {k: {"frac": v["frac"], "achieved": v["achieved"], "peak": v["peak"], "unit": v["unit"]} for k, v in roof["other_roofs"].items()}},
     }
     run.close()
     return out

@@ -91,6 +91,9 @@ typedef struct pt_stats {
      * retiring/refilling lanes; extend_steps / (64 * sched_interior) is the lane utilisation of the interior loop */
     uint64_t sched_interior, sched_leaf, sched_refill;
     uint64_t special_rays;      /* rays (extend + connect) that took the two-wide walk: zero/denormal/non-finite components */
+    /* extend stage, traversal_stats only: node records / triangle records fetched, counting the lanes of one wave instruction
+     * that ask for the same record once (the vector memory pipeline serves them together): what the stage's loads cost */
+    uint64_t extend_unique_steps, extend_unique_tris;
 } pt_stats;
 
 /* ---- lifetime --------------------------------------------------------------

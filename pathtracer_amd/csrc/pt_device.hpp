@@ -86,6 +86,7 @@ struct Ctl {
     unsigned long long paths, extend_rays, shadow_rays, extend_steps, extend_tris, shadow_steps, shadow_tris, stack_overflows;
     unsigned long long sched_interior, sched_leaf, sched_refill;   // wave iterations by kind, extend stage, instrumented builds
     unsigned long long special_rays;                               // rays that took the two-wide, NaN-rejecting walk
+    unsigned long long unique_steps, unique_tris;                  // extend stage, instrumented builds: DISTINCT records fetched per wave instruction, summed
 };
 
 // ------------------------------------------------ deterministic elementary fns
@@ -370,7 +371,8 @@ template <bool ANYHIT, bool STATS, class Source>
 __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, unsigned long long* leafq, const Source& src,
                                              uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched, uint32_t refillMin,
                                              unsigned long long* specialRays) {
-    // sched[0..2] (STATS builds): wave iterations spent on interior steps, leaf steps, retire/refill
+    // sched[0..2] (STATS builds): wave iterations spent on interior steps, leaf steps, retire/refill; sched[3..4]: distinct quad
+    // records / triangles fetched per wave instruction, summed (wave-uniform counts)
     const uint32_t lane = laneId();
     const uint32_t totalWaves = gridDim.x * (blockDim.x / PT_WAVE);
     const uint32_t waveId = blockIdx.x * (blockDim.x / PT_WAVE) + threadIdx.x / PT_WAVE;
@@ -494,6 +496,17 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             if (refillable && 64u - (uint32_t)__popcll(interiorMask) - nLeaf >= refillMin) break;
             if (STATS) sched[0]++;
             PT_MARK("interior_begin");
+            if (STATS) {
+                // distinct quad records among the lanes that step now: what the vector memory pipeline pays for (lanes that
+                // ask for the same 16 bytes are served together)
+                const bool stepping = (int32_t)cur > 0 && !special;
+                unsigned long long m = __ballot(stepping);
+                while (m != 0ull) {
+                    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)__ffsll((long long)m) - 1);
+                    m &= ~__ballot(stepping && cur == c);
+                    sched[3]++;
+                }
+            }
             {
                 if ((int32_t)cur > 0 && !special) {
                     if (STATS) (*nsteps)++;
@@ -634,6 +647,14 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             const int32_t j = jO + (int32_t)kth;
             bool hit = false;
             float tt = 0.0f, tu = 0.0f, tv = 0.0f;
+            if (STATS) {
+                unsigned long long m = __ballot(busy);
+                while (m != 0ull) {
+                    const int32_t c = __builtin_amdgcn_readlane(j, (int)__ffsll((long long)m) - 1);
+                    m &= ~__ballot(busy && j == c);
+                    sched[4]++;
+                }
+            }
             if (busy) {
                 const float4* tp = sc.tri_hot + 3 * (size_t)j;
                 const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];

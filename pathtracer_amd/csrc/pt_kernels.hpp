@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene
     src.o = q.o[cur];
     src.d = q.d[cur];
     src.hit = q.hit;
-    uint32_t sched[3] = {0, 0, 0};
+    uint32_t sched[5] = {0, 0, 0, 0, 0};
     traverseWave<false, STATS>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
     if (STATS) {
         waveAdd64(&ctl->extend_steps, steps);
@@ -140,6 +140,8 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene
             atomicAdd(&ctl->sched_interior, (unsigned long long)sched[0]);
             atomicAdd(&ctl->sched_leaf, (unsigned long long)sched[1]);
             atomicAdd(&ctl->sched_refill, (unsigned long long)sched[2]);
+            atomicAdd(&ctl->unique_steps, (unsigned long long)sched[3]);
+            atomicAdd(&ctl->unique_tris, (unsigned long long)sched[4]);
         }
     }
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScen
     src.sd = q.sd;
     src.sc = q.sc;
     src.plane = q.plane;
-    uint32_t sched[3] = {0, 0, 0};
+    uint32_t sched[5] = {0, 0, 0, 0, 0};
     traverseWave<true, STATS>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
     if (STATS) {
         waveAdd64(&ctl->shadow_steps, steps);
@@ -543,7 +545,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
     unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
     uint32_t steps = 0, tris = 0, overflow = 0;
-    uint32_t sched[3] = {0, 0, 0};
+    uint32_t sched[5] = {0, 0, 0, 0, 0};
     // every wave traces its own 64 rays and never refills: the threshold is not used
     traverseWave<ANYHIT, false>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, 64u, &ctl->special_rays);
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);

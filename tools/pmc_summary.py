@@ -30,8 +30,10 @@ def main():
                 if "Start_Timestamp" in row and row["Start_Timestamp"]:
                     dur[short][0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
                     dur[short][1] += 1
+    # register counts are not printed: rocprofv3's VGPR_Count column is not the kernel's register count on gfx950
+    # (tools/kernel_resources.py reads the real figures from the code object)
     for short, m in sorted(meta.items()):
-        print(f"{short}: vgpr={m[0]} agpr={m[1]} sgpr={m[2]} lds={m[3]} scratch={m[4]}")
+        print(f"{short}: lds={m[3]} scratch={m[4]}")
     for (short, counter), (total, n) in sorted(acc.items()):
         print(f"{short:42s} {counter:36s} mean/dispatch {total / n:18.1f}  dispatches {n}")
 
