@@ -84,8 +84,20 @@ def render_state(width, height, sky=SKY):
     return rs
 
 
-def path_config(max_bounces=10, nee=0, rng_mode=0, tile_rank=0, tile_world=1):
-    return np.array([max_bounces, nee, rng_mode, tile_rank, tile_world], np.int32)
+LITERAL_GLSL_EXTEND, LITERAL_PACKED_NORMAL, LITERAL_RUNNING_MEAN = 1, 2, 4
+
+
+def path_config(max_bounces=10, nee=0, rng_mode=0, tile_rank=0, tile_world=1, literal=0):
+    """literal: reference GLSL behaviours the product path departs from (LITERAL_* flags), for the tests that measure the gap."""
+    return np.array([max_bounces, nee, rng_mode, tile_rank, tile_world, literal], np.int32)
+
+
+def second_statement(kind, rows):
+    """Two restatements of one helper on the same inputs (rows of 8 floats): see orc_second_statement in capi.cpp."""
+    rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 8)
+    a, b = np.zeros((rows.shape[0], 3), np.float32), np.zeros((rows.shape[0], 3), np.float32)
+    _chk(lib().orc_second_statement({"schlick": 0, "diffuse_direction": 1, "packed_normal": 2, "diffuse_throughput": 3}[kind], _p(rows), rows.shape[0], _p(a), _p(b)))
+    return a, b
 
 
 class Scene:
@@ -164,6 +176,14 @@ class Scene:
         if stats:
             r["stats"] = dict(steps=int(st[0]), tris=int(st[1]), rays=int(st[2]))
         return r
+
+    def intersect_glsl(self, rays, threads=1):
+        """The reference's GLSL closest-hit walk and triangle test (extend.glsl:171-299): dict(tri, t, normal, stack_peak, candidate_peak)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        tri, t, nrm, peaks = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32), np.zeros(2, np.int32)
+        _chk(lib().orc_intersect_glsl(self.h, _p(rays), n, _p(tri), _p(t), _p(nrm), _p(peaks), threads))
+        return dict(tri=tri, t=t, normal=nrm, stack_peak=int(peaks[0]), candidate_peak=int(peaks[1]))
 
     def occluded(self, rays, tmax, threads=1):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)

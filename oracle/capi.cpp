@@ -247,6 +247,62 @@ int orc_occluded(void* h, const float* rays, const float* tmax, int n, uint8_t* 
     ORC_CATCH
 }
 
+// The GLSL closest-hit walk + triangle test (extend.glsl:171-299) for n rays: triangle, distance, normalized hit normal;
+// peaks2 = { largest traversal stack, largest candidate list } over the rays (the shader's arrays hold 32 and 128).
+int orc_intersect_glsl(void* h, const float* rays, int n, int32_t* tri, float* t, float* normal3, int32_t* peaks2, int threads) {
+    ORC_TRY
+    const Accelerator& acc = ((OrcScene*)h)->scene.accelerator;
+    std::vector<int> peakS(std::max(1, threads), 0), peakC(std::max(1, threads), 0);
+    parallelFor(n, threads, [&](int a, int b, int tid) {
+        for (int i = a; i < b; i++) {
+            Ray r = MakeRay({rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, {rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]});
+            int sp = 0, cc = 0;
+            const GlslHit g = IntersectGlsl(acc, r, &sp, &cc);
+            tri[i] = g.Tri;
+            t[i] = g.Distance;
+            normal3[3 * i] = g.Normal.x; normal3[3 * i + 1] = g.Normal.y; normal3[3 * i + 2] = g.Normal.z;
+            peakS[tid] = std::max(peakS[tid], sp);
+            peakC[tid] = std::max(peakC[tid], cc);
+        }
+    });
+    if (peaks2) { peaks2[0] = *std::max_element(peakS.begin(), peakS.end()); peaks2[1] = *std::max_element(peakC.begin(), peakC.end()); }
+    ORC_CATCH
+}
+
+// Two statements of one helper side by side.  kind 0: schlick(direction3, normal3, n1, n2) -> 1 float each;
+// kind 1: cosine-weighted direction(normal3, seed bits) -> 3 floats each; kind 2: pack/unpack of a unit normal3 -> 3 floats
+// (out_b = the input); kind 3: diffuse throughput for (normal3, color3, seed bits): out_a = shade.glsl's brdf * cos / pdf over
+// the direction of kind 1, out_b = compute.glsl's plain `* color`.  in: n rows of 8 floats; out: n rows of 3 floats.
+int orc_second_statement(int kind, const float* in, int n, float* out_a, float* out_b) {
+    ORC_TRY
+    for (int i = 0; i < n; i++) {
+        const float* x = in + 8 * i;
+        float* a = out_a + 3 * i;
+        float* b = out_b + 3 * i;
+        uint32_t seedA, seedB;
+        memcpy(&seedA, &x[6], 4);
+        seedB = seedA;
+        if (kind == 0) {
+            a[0] = ProbeSchlick({x[0], x[1], x[2]}, {x[3], x[4], x[5]}, x[6], x[7]);
+            b[0] = SecondSchlick({x[0], x[1], x[2]}, {x[3], x[4], x[5]}, x[6], x[7]);
+            a[1] = a[2] = b[1] = b[2] = 0;
+        } else if (kind == 1) {
+            const Vec3 va = ProbeLambertSample({x[0], x[1], x[2]}, seedA), vb = SecondDiffuseReflection({x[0], x[1], x[2]}, seedB);
+            a[0] = va.x; a[1] = va.y; a[2] = va.z; b[0] = vb.x; b[1] = vb.y; b[2] = vb.z;
+        } else if (kind == 2) {
+            const Vec3 v = UnpackNormalGlsl(PackNormalGlsl({x[0], x[1], x[2]}));
+            a[0] = v.x; a[1] = v.y; a[2] = v.z; b[0] = x[0]; b[1] = x[1]; b[2] = x[2];
+        } else {
+            const Vec3 nrm{x[0], x[1], x[2]};
+            const Vec3 l = ProbeLambertSample(nrm, seedA);
+            const float color[3] = {x[3], x[4], x[5]};
+            ProbeDiffuseThroughput(nrm, l, color, a);
+            b[0] = 1.0f * color[0]; b[1] = 1.0f * color[1]; b[2] = 1.0f * color[2];
+        }
+    }
+    ORC_CATCH
+}
+
 // Camera.Set(position, target) for a width x height window; h may be NULL (empty scene, focal = 20).
 // Writes FrameState.Camera (the other FrameState fields are left untouched) and the focal distance.
 int orc_camera(void* h, const float* pos3, const float* target3, int width, int height, void* frame_state112, float* focal) {
@@ -270,6 +326,7 @@ static PathConfig mkcfg(const int32_t* cfg5) {
     c.rng_mode = cfg5[2];
     c.tile_rank = cfg5[3];
     c.tile_world = cfg5[4];
+    c.literal = cfg5[5];
     return c;
 }
 

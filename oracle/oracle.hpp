@@ -200,7 +200,25 @@ struct PathConfig {
     int nee = 0;           // next-event estimation at diffuse vertices: 0 off, 1 on, 2 on with multiple importance sampling
     int rng_mode = 0;      // 0 = reference seeding, 1 = decorrelated hash
     int tile_rank = 0, tile_world = 1;
+    // Literal behaviours of the reference's GLSL that the product path departs from, switchable for the tests that state how far
+    // apart the two are: 1 = closest hit by the walk and triangle test of extend.glsl:171-299 (hit normal from its u, v, w);
+    // 2 = the hit normal goes through packNormal / unpackNormal (16+16 bits, extend.glsl:23-27, shade.glsl:29-36);
+    // 4 = the pixel is the running mean of shade.glsl:89-96 (the output buffer then holds the image, not a sum).
+    int literal = 0;
 };
+enum { LITERAL_GLSL_EXTEND = 1, LITERAL_PACKED_NORMAL = 2, LITERAL_RUNNING_MEAN = 4 };
+
+// ---- the reference's GLSL statements, restated apart from the product path (second.cpp)
+struct GlslHit { float Distance; int32_t Tri; Vec3 Normal; };
+GlslHit IntersectGlsl(const Accelerator& acc, const Ray& ray, int* stack_peak, int* candidate_count);
+uint32_t PackNormalGlsl(Vec3 n);
+Vec3 UnpackNormalGlsl(uint32_t p);
+float SecondSchlick(Vec3 direction, Vec3 normal, float n1, float n2);
+Vec3 SecondDiffuseReflection(Vec3 normal, uint32_t& seed);
+// the product path's statements of the same helpers (wavefront.cpp), exposed for the comparison
+float ProbeSchlick(Vec3 direction, Vec3 normal, float n1, float n2);
+Vec3 ProbeLambertSample(Vec3 normal, uint32_t& seed);
+void ProbeDiffuseThroughput(Vec3 normal, Vec3 bounce, const float color[3], float out[3]);
 // deterministic elementary functions shared (by restatement, not by code) with the kernels
 float det_sin(float x);
 float det_cos(float x);

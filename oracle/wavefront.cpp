@@ -279,6 +279,14 @@ static Vec4 sampleGgx(const Material& mat, Vec3 world_n, Vec3 world_v, Vec3* wor
     return {f.x * g, f.y * g, f.z * g, 0.0f * g};
 }
 
+float ProbeSchlick(Vec3 direction, Vec3 normal, float n1, float n2) { return schlick(direction, normal, n1, n2); }
+Vec3 ProbeLambertSample(Vec3 normal, uint32_t& seed) { return lambertImportanceSample(normal, seed); }
+// shade.glsl:413-426 as RenderSamples applies it: throughput (1,1,1) * (color / pi) * dot(l, n) / (clamp(dot(n, l)) / pi)
+void ProbeDiffuseThroughput(Vec3 normal, Vec3 bounce, const float color[3], float out[3]) {
+    const float pdf = clamp01(Dot(normal, bounce)) * INVPI;
+    for (int k = 0; k < 3; k++) out[k] = pdf == 0 ? 0.0f : 1.0f * (color[k] * INVPI) * Dot(bounce, normal) / pdf;
+}
+
 static int pickLight(const LightTable& lt, float r) {
     // smallest i with r * total < cdf[i]
     float target = r * lt.totalArea;
@@ -314,7 +322,13 @@ void RenderSamples(const Scene& scene, const LightTable& lights, const RenderSta
                 hit.Tri = -1;
                 hit.U = hit.V = 0;
                 if (stats) stats->extend_rays++;
-                if (traversal == 0) acc.Intersect(ray, hit);
+                Vec3 glslNormal{0, 0, 0};
+                if (cfg.literal & LITERAL_GLSL_EXTEND) {
+                    const GlslHit g = IntersectGlsl(acc, ray, nullptr, nullptr);
+                    hit.Tri = g.Tri;
+                    if (g.Tri >= 0) hit.Distance = g.Distance;
+                    glslNormal = g.Normal;
+                } else if (traversal == 0) acc.Intersect(ray, hit);
                 else acc.IntersectCanonical(ray, hit, stats ? &stats->extend : nullptr);
 
                 // ---- shade (shade.glsl:349-459)
@@ -344,6 +358,8 @@ void RenderSamples(const Scene& scene, const LightTable& lights, const RenderSta
                 // u weighs V2, v weighs V3, 1-u-v weighs V1
                 const float w = 1.0f - hit.U - hit.V;
                 Vec3 normal = Normalize((tri.V1.Normal * w + tri.V2.Normal * hit.U) + tri.V3.Normal * hit.V);
+                if (cfg.literal & LITERAL_GLSL_EXTEND) normal = glslNormal;
+                if (cfg.literal & LITERAL_PACKED_NORMAL) normal = UnpackNormalGlsl(PackNormalGlsl(normal));   // storeHit / getHit, extend.glsl:124-131, shade.glsl:115-123
                 const float dist = hit.Distance;
                 Vec3 bounceDir{0, 0, 0};
                 Vec4 throughput = T;
@@ -441,7 +457,13 @@ void RenderSamples(const Scene& scene, const LightTable& lights, const RenderSta
                 }
             }
             float* px = sum + 4 * (size_t)pixel;
-            px[0] += plane.x; px[1] += plane.y; px[2] += plane.z; px[3] += plane.w;
+            if (cfg.literal & LITERAL_RUNNING_MEAN) {   // shade.glsl:89-96 with samples = FrameState.Samples of this frame
+                const float n = (float)fs.Samples;
+                px[0] = (px[0] * n + plane.x) / (n + 1.0f); px[1] = (px[1] * n + plane.y) / (n + 1.0f);
+                px[2] = (px[2] * n + plane.z) / (n + 1.0f); px[3] = (px[3] * n + plane.w) / (n + 1.0f);
+            } else {
+                px[0] += plane.x; px[1] += plane.y; px[2] += plane.z; px[3] += plane.w;
+            }
         }
     }
 }
