@@ -6,7 +6,10 @@
 // Result (200,000 shadow rays): soup 41.3 / 42.1 / 41.0 / 37.9 / 42.7 / 41.3 / 37.8 steps per ray (94.7 % occluded; an
 // occluded ray needs ~40 steps under every order, an unoccluded one 65.5); bundled scene 14.5 / 14.4 / 14.0 / 13.9 / 14.4 /
 // 14.4 / 13.8.  No order changes the picture: the soup's triangles are small against their boxes, so finding any occluder
-// costs about what finding the nearest one costs.
+// costs about what finding the nearest one costs.  Both alternatives were then built into the kernels and the oracle and
+// measured on the real frame (1M soup, 1080p, 64 spp; connect stage 61.3 ms with nearest first): slot order without a sort
+// 67.3 ms (42.0 steps per shadow ray instead of 39.5), longest stretch first 63.0 ms (39.4 steps: the render's own shadow
+// rays gain far less than the synthetic ones here, and the keys cost more arithmetic).  Nearest first stayed.
 #include "oracle.hpp"
 #include <cstdio>
 #include <cstring>

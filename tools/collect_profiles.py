@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""Copy a set of measured summaries from gpurun_out/ into profiles/ under a tag (run here after the GPU call).
+"""Copy a round's measured summaries from gpurun_out/ into profiles/ under a tag (run here after the GPU calls).
 
-The GPU call:   tools/pmc_bench.sh gpurun_out/final_pmc > gpurun_out/final_pmc_summary.txt
-                python bench.py > gpurun_out/final_cfg/bundled.json; python bench.py --workload c1|c3|c4|c5 ... > gpurun_out/final_cfg/<w>.json
-Then:           python tools/collect_profiles.py <tag>
+The GPU calls (see the round's notes in DESIGN.md for the exact commands):
+  python bench.py                                   > gpurun_out/<run>_bench.json            the default line (with cpu_baseline and the soup block)
+  python bench.py --workload c1|c3|c4|c5 --steps 3  > gpurun_out/<run>_cfg/<w>.json
+  tools/pmc_bench.sh gpurun_out/<run>_pmc_bundled                     > gpurun_out/<run>_pmc_bundled_summary.txt
+  tools/pmc_bench.sh gpurun_out/<run>_pmc_c3 --workload c3 --steps 1  > gpurun_out/<run>_pmc_c3_summary.txt
+Then:  python tools/collect_profiles.py <tag> <run> <bench-json-name>
 """
 import glob
 import json
@@ -16,41 +19,59 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main():
-    tag = sys.argv[1]
-    out, prof = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+def counters(path, kernel="void k_extend<false>"):
     vals = {}
-    for line in open(os.path.join(out, "final_pmc_summary.txt")):
-        m = re.match(r"void k_extend<false>\s+(\S+)\s+mean/dispatch\s+([\d.]+)", line)
+    for line in open(path):
+        m = re.match(re.escape(kernel) + r"\s+(\S+)\s+mean/dispatch\s+([\d.]+)", line)
         if m:
             vals[m.group(1)] = float(m.group(2))
+    return vals
+
+
+def traffic_entry(vals, source, command):
     rd = 128 * vals["TCC_EA0_RDREQ_128B_sum"] + 64 * vals["TCC_EA0_RDREQ_64B_sum"] + 32 * vals["TCC_EA0_RDREQ_32B_sum"]
     wr = 64 * vals["TCC_EA0_WRREQ_64B_sum"] + 32 * (vals["TCC_EA0_WRREQ_sum"] - vals["TCC_EA0_WRREQ_64B_sum"])
-    tpath = os.path.join(prof, "traffic.json")
-    t = json.load(open(tpath))
-    b = t["bundled"]
-    b["extend_hbm_bytes_per_launch"], b["read_bytes_per_launch"], b["write_bytes_per_launch"] = rd + wr, rd, wr
-    b["tcc_hit_rate"] = vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])
-    b["method"] = re.sub(r"read [\d.]+ MB in its own pass", "read %.1f MB in its own pass" % (vals["FETCH_SIZE"] * 1024 / 1e6), b["method"])
-    b["valu_busy"] = vals["SQ_INSTS_VALU"] * 4 / (1024 * vals["GRBM_GUI_ACTIVE"] / 8)
-    b["valu_busy_method"] = "SQ_INSTS_VALU (wave instructions, 4 cycles each on a 16-lane SIMD) over 1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs, k_extend<false>, mean per dispatch"
-    json.dump(t, open(tpath, "w"), indent=1)
-    shutil.copy(os.path.join(out, "final_pmc_summary.txt"), os.path.join(prof, f"{tag}_bench_bundled_pmc.txt"))
-    stats = sorted(glob.glob(os.path.join(out, "final_pmc", "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
-    shutil.copy(stats[-1], os.path.join(prof, f"{tag}_bench_bundled_kernel_stats.csv"))
-    for w in ("c1", "c3", "c4", "c5"):
-        shutil.copy(os.path.join(out, "final_cfg", w + ".json"), os.path.join(prof, f"{tag}_cfg_{w}.json"))
-    d = json.load(open(os.path.join(out, "final_cfg", "bundled.json")))
-    d["roofline"]["traffic"] = rd + wr          # the bench line read the previous traffic.json
-    d["roofline"]["valu_busy"] = b["valu_busy"]
-    open(os.path.join(prof, f"{tag}_bench_bundled.json"), "w").write(json.dumps(d) + "\n")
-    table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_configs_md.py"), os.path.join(out, "final_cfg")], capture_output=True, text=True, check=True).stdout
-    cpath = os.path.join(prof, f"{tag}_configs.md")
-    s = open(cpath).read()
-    a, z = s.index("| config |"), s.index("\nc1 is one sample")
-    open(cpath, "w").write(s[:a] + table + s[z:])
-    valu_busy = vals["SQ_INSTS_VALU"] * 4 / (1024 * vals["GRBM_GUI_ACTIVE"] / 8)
-    print(f"bench {d['value']:.0f} Mrays/s, {d['ms_per_step']:.2f} ms; extend launch {d['roofline']['avg_launch_ms']:.3f} ms; traffic {(rd + wr) / 1e6:.0f} MB; VALU busy {valu_busy:.2f}")
+    simd_cycles = 1024 * vals["GRBM_GUI_ACTIVE"] / 8
+    return {
+        "extend_hbm_bytes_per_launch": rd + wr, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+        "method": "rocprofv3 --pmc, separate passes: TCC_EA0_RDREQ{,_32B,_64B,_128B}_sum and TCC_EA0_WRREQ{,_64B}_sum of k_extend<false>, mean per dispatch; "
+                  "read bytes = 128*n128 + 64*n64 + 32*n32, write bytes = 64*n64 + 32*(n - n64) (FETCH_SIZE tallies 128-B requests as 64 B on gfx950; the "
+                  "request-size breakdown is the figure used). L2 memory-side requests: Infinity-Cache hits are included, so this is an upper bound on HBM bytes.",
+        "tcc_hit_rate": vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]),
+        "valu_busy": vals["SQ_INSTS_VALU"] * 4 / simd_cycles,
+        "valu_busy_method": "SQ_INSTS_VALU (wave instructions, 4 cycles each on a 16-lane SIMD) over 1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs, k_extend<false>, mean per dispatch",
+        "waves_per_simd": vals["SQ_WAVE_CYCLES"] / simd_cycles,
+        "waves_per_simd_method": "SQ_WAVE_CYCLES over SIMD cycles: resident waves per SIMD averaged over the launch (the kernel is compiled for 6, the grid fills 6)",
+        "wait_fraction": vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"],
+        "source": source, "command": command,
+    }
+
+
+def main():
+    tag, run, bench_name = sys.argv[1], sys.argv[2], sys.argv[3]
+    out, prof = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+    traffic = {}
+    for w, args in (("bundled", ""), ("c3", " --workload c3 --steps 1")):
+        summary = os.path.join(out, f"{run}_pmc_{w}_summary.txt")
+        shutil.copy(summary, os.path.join(prof, f"{tag}_bench_{w}_pmc.txt"))
+        traffic[w] = traffic_entry(counters(summary), f"profiles/{tag}_bench_{w}_pmc.txt", "python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-secondary" + args)
+        stats = sorted(glob.glob(os.path.join(out, f"{run}_pmc_{w}", "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+        shutil.copy(stats[-1], os.path.join(prof, f"{tag}_bench_{w}_kernel_stats.csv"))
+    json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+    cfg = os.path.join(out, f"{run}_cfg")
+    shutil.copy(os.path.join(out, bench_name), os.path.join(cfg, "bundled.json"))
+    for w in ("bundled", "c1", "c3", "c4", "c5"):
+        d = json.load(open(os.path.join(cfg, w + ".json")))
+        if w in traffic:    # the line was printed with the previous round's traffic.json
+            d["roofline"]["traffic"] = traffic[w]["extend_hbm_bytes_per_launch"]
+            d["roofline"]["traffic_source"] = traffic[w]["source"] + " (committed PMC passes of the same command, not measured by this run)"
+        name = f"{tag}_bench_bundled.json" if w == "bundled" else f"{tag}_cfg_{w}.json"
+        open(os.path.join(prof, name), "w").write(json.dumps(d) + "\n")
+    table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_configs_md.py"), cfg], capture_output=True, text=True, check=True).stdout
+    open(os.path.join(prof, f"{tag}_configs.md"), "w").write(table)
+    for w, t in traffic.items():
+        print(f"{w}: HBM-side traffic {t['extend_hbm_bytes_per_launch'] / 1e6:.0f} MB per extend launch, L2 hit rate {t['tcc_hit_rate']:.2f}, VALU busy {t['valu_busy']:.2f}, "
+              f"waves/SIMD {t['waves_per_simd']:.2f}")
 
 
 if __name__ == "__main__":
