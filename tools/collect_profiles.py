@@ -40,8 +40,10 @@ def traffic_entry(vals, source, command):
         "tcc_hit_rate": vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]),
         "valu_busy": vals["SQ_INSTS_VALU"] * 4 / simd_cycles,
         "valu_busy_method": "SQ_INSTS_VALU (wave instructions, 4 cycles each on a 16-lane SIMD) over 1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs, k_extend<false>, mean per dispatch",
-        "waves_per_simd": vals["SQ_WAVE_CYCLES"] / simd_cycles,
-        "waves_per_simd_method": "SQ_WAVE_CYCLES over SIMD cycles: resident waves per SIMD averaged over the launch (the kernel is compiled for 6, the grid fills 6)",
+        "waves_per_simd": 4 * vals["SQ_WAVE_CYCLES"] / simd_cycles,
+        "waves_per_simd_method": "4 x SQ_WAVE_CYCLES over SIMD clocks: resident waves per SIMD averaged over the launch.  SQ_WAVE_CYCLES is taken to count in units "
+                                 "of 4 clocks here (the raw quotient is 1.3-1.4 for launches whose grid places exactly 6 waves on every SIMD and keeps them until "
+                                 "the queue runs dry); the kernel is compiled for 6 waves per SIMD and the grid fills 6",
         "wait_fraction": vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"],
         "source": source, "command": command,
     }
