@@ -489,6 +489,18 @@ def test_bad_bvh_rejected(pa, ob, bundled):
         wf.upload_scene(mats, badt, nodes)
     with pytest.raises(pa.PtError):
         wf.allocate(64, 64) or wf.invoke(bundled_view(bundled, 64, 64))   # no scene uploaded
+    # a refused scene — by either path — leaves the installed one as it was
+    wf.upload_scene(mats, tris, nodes)
+    fs = bundled_view(bundled, 64, 64)
+    wf.invoke(fs, spp=2, max_bounces=3)
+    before = wf.read_image()
+    with pytest.raises(pa.PtError):
+        wf.upload_scene(mats, badt, nodes)
+    with pytest.raises(pa.PtError):
+        wf.build_scene(mats, badt)            # the GPU build notices the material index only after building
+    fs["samples"] = 0
+    wf.invoke(fs, spp=2, max_bounces=3)
+    assert np.array_equal(bits(wf.read_image()), bits(before))
     wf.close()
 
 
