@@ -15,6 +15,9 @@
  * that replaces Wavefront.cs:40-56 gets them from the same create / render /
  * read-image calls; tile sharding and the RCCL gather are inside the library.
  *
+ * Every call makes the context's GPU (for a multi-GPU context: one of its GPUs)
+ * the calling thread's current HIP device and leaves it so.
+ *
  * All functions return PT_OK (0) or a negative pt_status; nothing throws across
  * the boundary.  pt_last_error() returns a message owned by the context (or by
  * the library when ctx is NULL).  A context is used by one thread at a time.

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy a round's measured summaries from gpurun_out/ into profiles/ under a tag (run here after the GPU calls).
 
-The GPU calls (see the round's notes in DESIGN.md for the exact commands):
+The GPU calls:
   python bench.py                                   > gpurun_out/<run>_bench.json            the default line (with cpu_baseline and the soup block)
   python bench.py --workload c1|c3|c4|c5 --steps 3  > gpurun_out/<run>_cfg/<w>.json
   tools/pmc_bench.sh gpurun_out/<run>_pmc_bundled                     > gpurun_out/<run>_pmc_bundled_summary.txt

@@ -36,7 +36,7 @@ def assembly():
 
 
 def function_lines(lines, prefix):
-    start = next(i for i, l in enumerate(lines) if l.startswith(prefix) and l.rstrip().endswith(":") is False and ":" in l.split(";")[0])
+    start = next(i for i, l in enumerate(lines) if l.startswith(prefix) and ":" in l.split(";")[0])   # the label line "<mangled name>:"
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
     return lines[start + 1:end]
 
