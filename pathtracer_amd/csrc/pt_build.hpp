@@ -14,7 +14,12 @@
 //     ranks from wave ballots) that keeps every CU busy on the few huge nodes at the top of the tree;
 //   * the tree is built level by level with arbitrary node numbers and renumbered at the end into the
 //     reference's order: a node's two children, then everything below the left child, then everything
-//     below the right child (Accelerator.cs:136-177).
+//     below the right child (Accelerator.cs:136-177);
+//   * a node of at most PTB_SMALL primitives leaves the level-by-level scheme: one thread builds everything
+//     below it the way the reference's recursion does (Subdivide, left before right), which hands out the
+//     reference's relative node numbers as it goes.  The deep levels of a large tree are millions of tiny
+//     nodes; per level they cost a pass over all primitives and global atomics per primitive, per thread
+//     they cost a few dozen primitives that stay in cache.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,6 +36,10 @@ namespace ptbuild {
 #define PTB_LEAF 3             // Accelerator.cs:11
 #define PTB_BINS 8             // Accelerator.cs:12
 #define PTB_CHUNK 2048         // primitives per block of the chunked partition; nodes at least this large take it
+#ifndef PTB_SMALL
+#define PTB_SMALL 64           // nodes of at most this many primitives are finished by one thread each
+#endif
+#define PTB_COPIES 16          // private copies of a block's bin table in LDS (lane & 15 picks one): a sixteenth of the conflicts
 
 struct Tri112 { float v[3][8]; int32_t material; int32_t pad[3]; };   // Triangle.cs:7-13 (three 32-byte vertices)
 struct Node32 { float mn[3], mx[3]; int32_t leftFirst, count; };      // Node.cs:5-10
@@ -61,7 +70,7 @@ struct BNode {
     uint32_t block;      // final index of its children pair
     uint32_t index;      // final index of the node
     uint32_t level;      // depth (root 0)
-    uint32_t aux;        // repack: quad index of an interior node at an even depth / big-leaf row of a large leaf
+    uint32_t aux;        // PTB_NONE; for the root of a thread-built subtree its own creation index; for the nodes below it that root's
 };
 
 // per active node of the running level
@@ -77,7 +86,7 @@ struct Split {
     uint32_t bmn[PTB_BINS][3], bmx[PTB_BINS][3];   // bin domains (keys)
 };
 
-struct Counters { uint32_t nodes, next_active, sort_segments, large, chunks, pad[3]; };
+struct Counters { uint32_t nodes, next_active, sort_segments, large, chunks, small, max_level, pad; };
 
 // MathF.Max (NaN-propagating IEEE maximum), Vector.cs:28-31
 __device__ inline float mathfMax(float x, float y) {
@@ -132,7 +141,7 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_prims(const Tri112* tris, uint32_
     else if (threadIdx.x < 6) atomicMax(&root_keys[threadIdx.x], s[threadIdx.x]);
 }
 
-__global__ void k_root(BNode* nodes, const uint32_t* root_keys, uint32_t n, Counters* ctr, uint32_t* active) {
+__global__ void k_root(BNode* nodes, const uint32_t* root_keys, uint32_t n, Counters* ctr, uint32_t* active, uint32_t* small) {
     BNode r{};
     for (int a = 0; a < 3; a++) {
         r.mn[a] = n ? fval(root_keys[a]) : __builtin_huge_valf();       // Box.Negative, Box.cs:14-18
@@ -142,12 +151,17 @@ __global__ void k_root(BNode* nodes, const uint32_t* root_keys, uint32_t n, Coun
     r.count = (int32_t)n;
     r.left = -1;
     r.level = 0;
-    r.next_rank = n >= PTB_LEAF ? 0u : PTB_NONE;
+    const bool split = n >= PTB_LEAF, tiny = split && n <= PTB_SMALL;
+    r.next_rank = (split && !tiny) ? 0u : PTB_NONE;
+    r.aux = tiny ? 0u : PTB_NONE;
     nodes[0] = r;
     ctr->nodes = 1;
-    ctr->next_active = n >= PTB_LEAF ? 1u : 0u;
+    ctr->next_active = (split && !tiny) ? 1u : 0u;
     ctr->sort_segments = 0;
+    ctr->small = tiny ? 1u : 0u;
+    ctr->max_level = 0;
     active[0] = 0;
+    small[0] = 0;
 }
 
 // per active node: split axis, empty centroid range
@@ -164,21 +178,51 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_split_begin(const BNode* nodes, c
 
 __device__ inline float axisOf(float4 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
-// Accelerator.CentroidBounds along the split axis, Accelerator.cs:294-310
-__global__ void __launch_bounds__(PTB_BLOCK) k_centroid_range(const float4* cent, const uint32_t* order, const uint32_t* seg, uint32_t n, Split* sp) {
+// Accelerator.CentroidBounds along the split axis, Accelerator.cs:294-310.  A block walks `tiles` consecutive tiles of 256
+// positions and keeps the range of the node its current tile starts in in LDS; it goes to global memory only when that node
+// changes or the block ends, so the handful of nodes at the top of the tree do not receive an atomic from every tile of the
+// array (same-address atomics serialise: 78,000 of them cost 4 ms per level on 20M primitives).  A wave whose lanes all sit in
+// one node reduces its 64 keys with lane exchanges first.
+__global__ void __launch_bounds__(PTB_BLOCK) k_centroid_range(const float4* cent, const uint32_t* order, const uint32_t* seg, uint32_t n, Split* sp, uint32_t tiles) {
     __shared__ uint32_t s_min, s_max, s_rank;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (threadIdx.x == 0) {
-        s_min = PTB_KEY_POS_INF;
-        s_max = PTB_KEY_NEG_INF;
-        s_rank = seg[blockIdx.x * blockDim.x];   // the block's first position is always inside the array
-    }
+    if (threadIdx.x == 0) { s_min = PTB_KEY_POS_INF; s_max = PTB_KEY_NEG_INF; s_rank = PTB_NONE; }
     __syncthreads();
-    const uint32_t r = i < n ? seg[i] : PTB_NONE;
-    if (r != PTB_NONE) {
-        const uint32_t k = fkey(axisOf(cent[order[i]], sp[r].axis));
-        if (r == s_rank) { atomicMin(&s_min, k); atomicMax(&s_max, k); }
-        else { atomicMin(&sp[r].cmin, k); atomicMax(&sp[r].cmax, k); }
+    for (uint32_t tile = 0; tile < tiles; tile++) {
+        const uint32_t base = (blockIdx.x * tiles + tile) * PTB_BLOCK;
+        if (base >= n) break;
+        const uint32_t rank0 = seg[base];
+        if (rank0 != s_rank) {            // block-uniform: flush what was gathered for the previous node
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if (s_rank != PTB_NONE && s_min != PTB_KEY_POS_INF) { atomicMin(&sp[s_rank].cmin, s_min); atomicMax(&sp[s_rank].cmax, s_max); }
+                s_min = PTB_KEY_POS_INF; s_max = PTB_KEY_NEG_INF; s_rank = rank0;
+            }
+            __syncthreads();
+        }
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t r = i < n ? seg[i] : PTB_NONE;
+        const bool valid = r != PTB_NONE;
+        const uint32_t k = valid ? fkey(axisOf(cent[order[i]], sp[r].axis)) : 0u;
+        const unsigned long long vm = __ballot(valid);
+        if (vm != 0ull) {
+            const int firstLane = (int)__ffsll((long long)vm) - 1;
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, firstLane);
+            if (__ballot(valid && r == r0) == vm) {
+                uint32_t lo = valid ? k : PTB_KEY_POS_INF, hi = valid ? k : PTB_KEY_NEG_INF;
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint32_t a = (uint32_t)__shfl_xor((int)lo, off), b2 = (uint32_t)__shfl_xor((int)hi, off);
+                    lo = a < lo ? a : lo;
+                    hi = b2 > hi ? b2 : hi;
+                }
+                if ((int)(threadIdx.x & 63u) == firstLane) {
+                    if (r0 == rank0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+                    else { atomicMin(&sp[r0].cmin, lo); atomicMax(&sp[r0].cmax, hi); }
+                }
+            } else if (valid) {
+                if (r == rank0) { atomicMin(&s_min, k); atomicMax(&s_max, k); }
+                else { atomicMin(&sp[r].cmin, k); atomicMax(&sp[r].cmax, k); }
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_rank != PTB_NONE && s_min != PTB_KEY_POS_INF) {
@@ -203,44 +247,74 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_split_bins(uint32_t n_active, Spl
     }
 }
 
-// Accelerator.cs:215-227: bin of every primitive, bin counts and domains
+// Accelerator.cs:215-227: bin of every primitive, bin counts and domains.  Tiles and the LDS table of the current tile's first
+// node as in k_centroid_range; the table is kept PTB_COPIES times so that the 256 threads do not all queue on the same eight
+// counters.
 __global__ void __launch_bounds__(PTB_BLOCK) k_bin(const float4* cent, const float4* pmin, const float4* pmax, const uint32_t* order, const uint32_t* seg,
-                                                   uint32_t n, Split* sp, uint8_t* bin_of) {
-    __shared__ uint32_t s_cnt[PTB_BINS], s_mn[PTB_BINS][3], s_mx[PTB_BINS][3], s_rank;
-    if (threadIdx.x < PTB_BINS) {
-        s_cnt[threadIdx.x] = 0;
-        for (int a = 0; a < 3; a++) { s_mn[threadIdx.x][a] = PTB_KEY_POS_INF; s_mx[threadIdx.x][a] = PTB_KEY_NEG_INF; }
-    }
-    if (threadIdx.x == 0) s_rank = seg[blockIdx.x * blockDim.x];
+                                                   uint32_t n, Split* sp, uint8_t* bin_of, uint32_t tiles) {
+    __shared__ uint32_t s_cnt[PTB_COPIES][PTB_BINS], s_mn[PTB_COPIES][PTB_BINS][3], s_mx[PTB_COPIES][PTB_BINS][3], s_rank;
+    auto clearTable = [&]() {
+        for (uint32_t t = threadIdx.x; t < PTB_COPIES * PTB_BINS; t += PTB_BLOCK) {
+            const uint32_t c = t / PTB_BINS, j = t % PTB_BINS;
+            s_cnt[c][j] = 0;
+            for (int a = 0; a < 3; a++) { s_mn[c][j][a] = PTB_KEY_POS_INF; s_mx[c][j][a] = PTB_KEY_NEG_INF; }
+        }
+    };
+    auto flushTable = [&]() {   // all threads call it between barriers
+        if (threadIdx.x < PTB_BINS && s_rank != PTB_NONE) {
+            const int j = threadIdx.x;
+            uint32_t cnt = 0, mn[3] = {PTB_KEY_POS_INF, PTB_KEY_POS_INF, PTB_KEY_POS_INF}, mx[3] = {PTB_KEY_NEG_INF, PTB_KEY_NEG_INF, PTB_KEY_NEG_INF};
+            for (int c = 0; c < PTB_COPIES; c++) {
+                cnt += s_cnt[c][j];
+                for (int a = 0; a < 3; a++) { mn[a] = s_mn[c][j][a] < mn[a] ? s_mn[c][j][a] : mn[a]; mx[a] = s_mx[c][j][a] > mx[a] ? s_mx[c][j][a] : mx[a]; }
+            }
+            if (cnt != 0) {
+                Split& g = sp[s_rank];
+                atomicAdd(&g.cnt[j], cnt);
+                for (int a = 0; a < 3; a++) { atomicMin(&g.bmn[j][a], mn[a]); atomicMax(&g.bmx[j][a], mx[a]); }
+            }
+        }
+    };
+    clearTable();
+    if (threadIdx.x == 0) s_rank = PTB_NONE;
     __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t r = i < n ? seg[i] : PTB_NONE;
-    if (r != PTB_NONE && sp[r].usable) {
-        const Split& s = sp[r];
-        const uint32_t id = order[i];
-        const float c = axisOf(cent[id], s.axis);
-        const float b = (c - s.k0) * s.k1;
-        int j = (int)b;
-        j = j < 0 ? 0 : (j > PTB_BINS - 1 ? PTB_BINS - 1 : j);   // only non-finite input can leave the range (the C# build throws there)
-        bin_of[i] = (uint8_t)j;
-        const float4 lo = pmin[id], hi = pmax[id];
-        const uint32_t klo[3] = {fkey(lo.x), fkey(lo.y), fkey(lo.z)}, khi[3] = {fkey(hi.x), fkey(hi.y), fkey(hi.z)};
-        if (r == s_rank) {
-            atomicAdd(&s_cnt[j], 1u);
-            for (int a = 0; a < 3; a++) { atomicMin(&s_mn[j][a], klo[a]); atomicMax(&s_mx[j][a], khi[a]); }
-        } else {
-            Split& g = sp[r];
-            atomicAdd(&g.cnt[j], 1u);
-            for (int a = 0; a < 3; a++) { atomicMin(&g.bmn[j][a], klo[a]); atomicMax(&g.bmx[j][a], khi[a]); }
+    for (uint32_t tile = 0; tile < tiles; tile++) {
+        const uint32_t base = (blockIdx.x * tiles + tile) * PTB_BLOCK;
+        if (base >= n) break;
+        const uint32_t rank0 = seg[base];
+        if (rank0 != s_rank) {            // block-uniform
+            __syncthreads();
+            flushTable();
+            __syncthreads();
+            clearTable();
+            if (threadIdx.x == 0) s_rank = rank0;
+            __syncthreads();
+        }
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t r = i < n ? seg[i] : PTB_NONE;
+        if (r != PTB_NONE && sp[r].usable) {
+            const Split& s = sp[r];
+            const uint32_t id = order[i];
+            const float c = axisOf(cent[id], s.axis);
+            const float b = (c - s.k0) * s.k1;
+            int j = (int)b;
+            j = j < 0 ? 0 : (j > PTB_BINS - 1 ? PTB_BINS - 1 : j);   // only non-finite input can leave the range (the C# build throws there)
+            bin_of[i] = (uint8_t)j;
+            const float4 lo = pmin[id], hi = pmax[id];
+            const uint32_t klo[3] = {fkey(lo.x), fkey(lo.y), fkey(lo.z)}, khi[3] = {fkey(hi.x), fkey(hi.y), fkey(hi.z)};
+            if (r == rank0) {
+                const uint32_t cp = threadIdx.x & (PTB_COPIES - 1u);
+                atomicAdd(&s_cnt[cp][j], 1u);
+                for (int a = 0; a < 3; a++) { atomicMin(&s_mn[cp][j][a], klo[a]); atomicMax(&s_mx[cp][j][a], khi[a]); }
+            } else {
+                Split& g = sp[r];
+                atomicAdd(&g.cnt[j], 1u);
+                for (int a = 0; a < 3; a++) { atomicMin(&g.bmn[j][a], klo[a]); atomicMax(&g.bmx[j][a], khi[a]); }
+            }
         }
     }
     __syncthreads();
-    if (threadIdx.x < PTB_BINS && s_rank != PTB_NONE && s_cnt[threadIdx.x] != 0) {
-        Split& g = sp[s_rank];
-        const int j = threadIdx.x;
-        atomicAdd(&g.cnt[j], s_cnt[j]);
-        for (int a = 0; a < 3; a++) { atomicMin(&g.bmn[j][a], s_mn[j][a]); atomicMax(&g.bmx[j][a], s_mx[j][a]); }
-    }
+    flushTable();
 }
 
 // Box.Union(a, b) with a = a bin's domain, b = the running box (Box.cs:81-88)
@@ -254,7 +328,7 @@ __device__ inline void unionInto(float* mn, float* mx, const uint32_t* kmn, cons
 
 // Accelerator.cs:229-262 (the sweep over the 7 split planes) and Accelerator.cs:150-176 (the two children)
 __global__ void __launch_bounds__(PTB_BLOCK) k_split_decide(BNode* nodes, uint32_t n_active, Split* sp, Counters* ctr, uint32_t* next_active,
-                                                            uint32_t* sort_begin, uint32_t* sort_end, uint32_t* large_rank, uint32_t* chunk_owner) {
+                                                            uint32_t* sort_begin, uint32_t* sort_end, uint32_t* large_rank, uint32_t* small) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_active) return;
     Split& s = sp[r];
@@ -294,9 +368,18 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_split_decide(BNode* nodes, uint32
     R.count = count - best;
     L.left = R.left = -1;
     L.level = R.level = nd.level + 1u;
-    L.next_rank = L.count >= PTB_LEAF ? atomicAdd(&ctr->next_active, 1u) : PTB_NONE;
-    R.next_rank = R.count >= PTB_LEAF ? atomicAdd(&ctr->next_active, 1u) : PTB_NONE;
     const uint32_t at = atomicAdd(&ctr->nodes, 2u);
+    // a child goes on: to the next level's active list, or — small enough — to the list of subtrees one thread finishes
+    L.next_rank = R.next_rank = PTB_NONE;
+    L.aux = R.aux = PTB_NONE;
+    if (L.count >= PTB_LEAF) {
+        if (L.count <= PTB_SMALL) { L.aux = at; small[atomicAdd(&ctr->small, 1u)] = at; }
+        else L.next_rank = atomicAdd(&ctr->next_active, 1u);
+    }
+    if (R.count >= PTB_LEAF) {
+        if (R.count <= PTB_SMALL) { R.aux = at + 1u; small[atomicAdd(&ctr->small, 1u)] = at + 1u; }
+        else R.next_rank = atomicAdd(&ctr->next_active, 1u);
+    }
     nodes[at] = L;
     nodes[at + 1] = R;
     if (L.next_rank != PTB_NONE) next_active[L.next_rank] = at;
@@ -308,8 +391,7 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_split_decide(BNode* nodes, uint32
     if (count >= PTB_CHUNK) {
         s.chunks = ((uint32_t)count + PTB_CHUNK - 1u) / PTB_CHUNK;
         s.chunk_base = atomicAdd(&ctr->chunks, s.chunks);
-        large_rank[atomicAdd(&ctr->large, 1u)] = r;
-        for (uint32_t k = 0; k < s.chunks; k++) chunk_owner[s.chunk_base + k] = r;
+        large_rank[atomicAdd(&ctr->large, 1u)] = r;   // k_chunk_owner spreads r over the node's chunks
     } else {
         const uint32_t k = atomicAdd(&ctr->sort_segments, 1u);
         sort_begin[k] = (uint32_t)nd.first;
@@ -318,6 +400,12 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_split_decide(BNode* nodes, uint32
 }
 
 // ---- chunked stable partition of the large nodes
+// pass 0: every chunk learns which large node it belongs to (one block per large node)
+__global__ void __launch_bounds__(PTB_BLOCK) k_chunk_owner(const Split* sp, const uint32_t* large_rank, uint32_t* chunk_owner) {
+    const uint32_t r = large_rank[blockIdx.x];
+    const Split& s = sp[r];
+    for (uint32_t k = threadIdx.x; k < s.chunks; k += PTB_BLOCK) chunk_owner[s.chunk_base + k] = r;
+}
 // pass 1: bin histogram of every chunk
 __global__ void __launch_bounds__(PTB_BLOCK) k_chunk_count(const BNode* nodes, const Split* sp, const uint32_t* chunk_owner, const uint8_t* bin_of, uint32_t* chunk_cnt) {
     __shared__ uint32_t s_cnt[PTB_BINS];
@@ -415,11 +503,115 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_reassign(const BNode* nodes, cons
     seg[i] = next;
 }
 
+// ---- small subtrees: Accelerator.Subdivide (Accelerator.cs:136-177) with Parition (:188-280) on one thread per subtree.
+// order[first, first + count) of the subtree's root belongs to this thread alone (tmp and bin_of at the same positions are its
+// scratch).  Nodes are taken from the shared counter two at a time; visiting left before right, as the recursion does, makes the
+// k-th pair this thread allocates the pair at relative index 2k of the reference's numbering of the subtree, so `index` (of the
+// node) and `block` (of its children pair) are written as relative numbers and k_small_finish adds the root's base later.
+__global__ void __launch_bounds__(64) k_small_subtrees(BNode* nodes, const uint32_t* small, uint32_t n_small, const float4* cent, const float4* pmin,
+                                                       const float4* pmax, uint32_t* order, uint32_t* tmp, uint8_t* bin_of, Counters* ctr) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_small) return;
+    const uint32_t root = small[t];
+    const float inf = __builtin_huge_valf();
+    int32_t stack[PTB_SMALL];
+    int sp = 0;
+    uint32_t pairs = 0, maxLevel = nodes[root].level;
+    stack[sp++] = (int32_t)root;
+    while (sp > 0) {
+        const int32_t idx = stack[--sp];
+        const BNode nd = nodes[idx];
+        if (nd.count < PTB_LEAF) continue;                                   // Accelerator.cs:140-143
+        const int axis = domainOf(nd.mn, nd.mx);
+        const int first = nd.first, count = nd.count;
+        float cmin = inf, cmax = -inf;                                       // CentroidBounds, Accelerator.cs:294-310
+        for (int i = first; i < first + count; i++) {
+            const float c = axisOf(cent[order[i]], axis);
+            cmin = c < cmin ? c : cmin;
+            cmax = c > cmax ? c : cmax;
+        }
+        const float k0 = cmin, l = cmax - k0;
+        if (l < PTB_EPSILON) continue;                                       // Accelerator.cs:203-204
+        const float k1 = ((float)PTB_BINS - PTB_EPSILON) / l;
+        int cnt[PTB_BINS];
+        float bmn[PTB_BINS][3], bmx[PTB_BINS][3];
+        for (int j = 0; j < PTB_BINS; j++) { cnt[j] = 0; for (int a = 0; a < 3; a++) { bmn[j][a] = inf; bmx[j][a] = -inf; } }
+        for (int i = first; i < first + count; i++) {                        // Accelerator.cs:215-227
+            const uint32_t id = order[i];
+            const float b = (axisOf(cent[id], axis) - k0) * k1;
+            int j = (int)b;
+            j = j < 0 ? 0 : (j > PTB_BINS - 1 ? PTB_BINS - 1 : j);
+            bin_of[i] = (uint8_t)j;
+            cnt[j]++;
+            const float4 lo = pmin[id], hi = pmax[id];
+            bmx[j][0] = hi.x > bmx[j][0] ? hi.x : bmx[j][0]; bmx[j][1] = hi.y > bmx[j][1] ? hi.y : bmx[j][1]; bmx[j][2] = hi.z > bmx[j][2] ? hi.z : bmx[j][2];
+            bmn[j][0] = lo.x < bmn[j][0] ? lo.x : bmn[j][0]; bmn[j][1] = lo.y < bmn[j][1] ? lo.y : bmn[j][1]; bmn[j][2] = lo.z < bmn[j][2] ? lo.z : bmn[j][2];
+        }
+        int best = -1, bestPlane = 0;                                        // the sweep, Accelerator.cs:229-262
+        float cost = areaOf(nd.mn, nd.mx) * (float)count;
+        int ln = 0, rn = count;
+        float lmn[3] = {inf, inf, inf}, lmx[3] = {-inf, -inf, -inf};
+        for (int i = 1; i < PTB_BINS; i++) {
+            ln += cnt[i - 1];
+            rn -= cnt[i - 1];
+            for (int a = 0; a < 3; a++) { lmx[a] = bmx[i - 1][a] > lmx[a] ? bmx[i - 1][a] : lmx[a]; lmn[a] = bmn[i - 1][a] < lmn[a] ? bmn[i - 1][a] : lmn[a]; }
+            float rmn[3] = {inf, inf, inf}, rmx[3] = {-inf, -inf, -inf};
+            for (int j = i; j < PTB_BINS; j++)
+                for (int a = 0; a < 3; a++) { rmx[a] = bmx[j][a] > rmx[a] ? bmx[j][a] : rmx[a]; rmn[a] = bmn[j][a] < rmn[a] ? bmn[j][a] : rmn[a]; }
+            const float c = (float)ln * areaOf(lmn, lmx) + (float)rn * areaOf(rmn, rmx);
+            if (c < cost) { best = ln; bestPlane = i; cost = c; }
+        }
+        if (best < 0) continue;                                              // Accelerator.cs:262: stays a leaf
+        // the reference rewrites the range bin by bin, order kept inside a bin (Accelerator.cs:264-279)
+        int offset[PTB_BINS];
+        for (int j = 0, acc = 0; j < PTB_BINS; j++) { offset[j] = acc; acc += cnt[j]; }
+        for (int i = first; i < first + count; i++) tmp[first + offset[bin_of[i]]++] = order[i];
+        for (int i = first; i < first + count; i++) order[i] = tmp[i];
+        BNode L{}, R{};
+        for (int a = 0; a < 3; a++) { L.mn[a] = inf; L.mx[a] = -inf; R.mn[a] = inf; R.mx[a] = -inf; }
+        for (int j = 0; j < PTB_BINS; j++) {
+            if (cnt[j] == 0) continue;
+            BNode& side = j < bestPlane ? L : R;
+            for (int a = 0; a < 3; a++) { side.mx[a] = bmx[j][a] > side.mx[a] ? bmx[j][a] : side.mx[a]; side.mn[a] = bmn[j][a] < side.mn[a] ? bmn[j][a] : side.mn[a]; }
+        }
+        L.first = first; L.count = best;
+        R.first = first + best; R.count = count - best;
+        L.left = R.left = -1;
+        L.level = R.level = nd.level + 1u;
+        maxLevel = L.level > maxLevel ? L.level : maxLevel;
+        L.next_rank = R.next_rank = PTB_NONE;
+        L.aux = R.aux = root;
+        L.index = 2u * pairs;
+        R.index = 2u * pairs + 1u;
+        const uint32_t at = atomicAdd(&ctr->nodes, 2u);
+        nodes[at] = L;
+        nodes[at + 1] = R;
+        nodes[idx].left = (int32_t)at;
+        nodes[idx].axis = axis;
+        if ((uint32_t)idx != root) nodes[idx].block = 2u * pairs;            // the root's own pair number comes from the levels above it
+        pairs++;
+        stack[sp++] = (int32_t)at + 1;                                       // left is subdivided first (Accelerator.cs:174-175)
+        stack[sp++] = (int32_t)at;
+    }
+    nodes[root].below = 2u * pairs;
+    atomicMax(&ctr->max_level, maxLevel);
+}
+// relative numbers of the thread-built nodes -> final ones, once the levels above have numbered the subtree roots
+__global__ void __launch_bounds__(PTB_BLOCK) k_small_finish(BNode* nodes, uint32_t lo, uint32_t hi) {
+    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    BNode& nd = nodes[i];
+    const uint32_t base = nodes[nd.aux].block;
+    nd.index += base;
+    if (nd.left >= 0) nd.block += base;
+}
+
 // ---- renumbering into the reference's order
 __global__ void __launch_bounds__(PTB_BLOCK) k_below(BNode* nodes, uint32_t lo, uint32_t hi) {
     const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hi) return;
     BNode& nd = nodes[i];
+    if (nd.aux == i) return;   // root of a thread-built subtree: the thread counted what lies below it
     nd.below = nd.left < 0 ? 0u : 2u + nodes[nd.left].below + nodes[nd.left + 1].below;
 }
 __global__ void __launch_bounds__(PTB_BLOCK) k_number(BNode* nodes, uint32_t lo, uint32_t hi) {
@@ -427,7 +619,7 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_number(BNode* nodes, uint32_t lo,
     if (i >= hi) return;
     BNode& nd = nodes[i];
     if (i == 0) { nd.index = 0; nd.block = 1; }
-    if (nd.left < 0) return;
+    if (nd.left < 0 || nd.aux == i) return;   // below the root of a thread-built subtree k_small_finish numbers
     BNode& L = nodes[nd.left];
     BNode& R = nodes[nd.left + 1];
     L.index = nd.block;
@@ -466,7 +658,7 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     const uint32_t maxActive = n / PTB_LEAF + 2u;
     float4 *pmin = nullptr, *pmax = nullptr, *cent = nullptr;
     uint32_t *order[2] = {nullptr, nullptr}, *seg = nullptr, *active[2] = {nullptr, nullptr}, *sortb = nullptr, *sorte = nullptr, *rootk = nullptr;
-    uint32_t *largeRank = nullptr, *chunkOwner = nullptr, *chunkCnt = nullptr;
+    uint32_t *largeRank = nullptr, *chunkOwner = nullptr, *chunkCnt = nullptr, *small = nullptr;
     const uint32_t maxChunks = 2u * (n / PTB_CHUNK) + 2u, maxLarge = n / PTB_CHUNK + 1u;
     uint8_t* bins[2] = {nullptr, nullptr};
     BNode* nodes = nullptr;
@@ -479,7 +671,9 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     const uint32_t nn = n ? n : 1u;
     const int cur = 0;
     int act = 0;
-    uint32_t nActive = 0;
+    uint32_t nActive = 0, levelNodes = 0, smallDepth = 0;
+    // the per-primitive passes of a level: about 4096 blocks, each over `tiles` consecutive tiles of 256 positions
+    const uint32_t nTiles = (nn + PTB_BLOCK - 1u) / PTB_BLOCK, tiles = nTiles > 4096u ? (nTiles + 4095u) / 4096u : 1u, tileGrid = (nTiles + tiles - 1u) / tiles;
     const uint32_t initKeys[6] = {PTB_KEY_POS_INF, PTB_KEY_POS_INF, PTB_KEY_POS_INF, PTB_KEY_NEG_INF, PTB_KEY_NEG_INF, PTB_KEY_NEG_INF};
 
     PTB_TRY(hipMalloc((void**)&pmin, (size_t)nn * 16));
@@ -494,6 +688,7 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     PTB_TRY(hipMalloc((void**)&sortb, (size_t)maxActive * 4));
     PTB_TRY(hipMalloc((void**)&sorte, (size_t)maxActive * 4));
     PTB_TRY(hipMalloc((void**)&rootk, 6 * 4));
+    PTB_TRY(hipMalloc((void**)&small, (size_t)maxActive * 4));
     PTB_TRY(hipMalloc((void**)&largeRank, (size_t)maxLarge * 4));
     PTB_TRY(hipMalloc((void**)&chunkOwner, (size_t)maxChunks * 4));
     PTB_TRY(hipMalloc((void**)&chunkCnt, (size_t)maxChunks * PTB_BINS * 4));
@@ -504,7 +699,7 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     PTB_TRY(hipMemsetAsync(seg, 0xFF, ((size_t)nn + PTB_BLOCK) * 4, stream));
     PTB_TRY(hipMemsetAsync(bins[0], 0, nn, stream));
     if (n) hipLaunchKernelGGL(k_prims, dim3(grid(n)), dim3(PTB_BLOCK), 0, stream, d_tris, n, pmin, pmax, cent, order[0], seg, rootk);
-    hipLaunchKernelGGL(k_root, dim3(1), dim3(1), 0, stream, nodes, rootk, n, ctr, active[0]);
+    hipLaunchKernelGGL(k_root, dim3(1), dim3(1), 0, stream, nodes, rootk, n, ctr, active[0], small);
     PTB_TRY(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
     PTB_TRY(hipStreamSynchronize(stream));
     levelStart.push_back(0);
@@ -518,17 +713,19 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     while (nActive > 0) {
         Counters z{};
         z.nodes = h.nodes;
+        z.small = h.small;
         PTB_TRY(hipMemcpyAsync(ctr, &z, sizeof(z), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(k_split_begin, dim3(grid(nActive)), dim3(PTB_BLOCK), 0, stream, nodes, active[act], nActive, sp);
-        hipLaunchKernelGGL(k_centroid_range, dim3(grid(n)), dim3(PTB_BLOCK), 0, stream, cent, order[cur], seg, n, sp);
+        hipLaunchKernelGGL(k_centroid_range, dim3(tileGrid), dim3(PTB_BLOCK), 0, stream, cent, order[cur], seg, n, sp, tiles);
         hipLaunchKernelGGL(k_split_bins, dim3(grid(nActive)), dim3(PTB_BLOCK), 0, stream, nActive, sp);
-        hipLaunchKernelGGL(k_bin, dim3(grid(n)), dim3(PTB_BLOCK), 0, stream, cent, pmin, pmax, order[cur], seg, n, sp, bins[cur]);
-        hipLaunchKernelGGL(k_split_decide, dim3(grid(nActive)), dim3(PTB_BLOCK), 0, stream, nodes, nActive, sp, ctr, active[act ^ 1], sortb, sorte, largeRank, chunkOwner);
+        hipLaunchKernelGGL(k_bin, dim3(tileGrid), dim3(PTB_BLOCK), 0, stream, cent, pmin, pmax, order[cur], seg, n, sp, bins[cur], tiles);
+        hipLaunchKernelGGL(k_split_decide, dim3(grid(nActive)), dim3(PTB_BLOCK), 0, stream, nodes, nActive, sp, ctr, active[act ^ 1], sortb, sorte, largeRank, small);
         PTB_TRY(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
         PTB_TRY(hipStreamSynchronize(stream));
         if (h.sort_segments > 0)   // sorted copies of the split nodes' ranges land in order[1]; k_reassign takes them over
             PTB_TRY(rocprim::segmented_radix_sort_pairs(tmp, tmpBytes, bins[0], bins[1], order[0], order[1], n, h.sort_segments, sortb, sorte, 0, 3, stream));
         if (h.chunks > 0) {
+            hipLaunchKernelGGL(k_chunk_owner, dim3(h.large), dim3(PTB_BLOCK), 0, stream, sp, largeRank, chunkOwner);
             hipLaunchKernelGGL(k_chunk_count, dim3(h.chunks), dim3(PTB_BLOCK), 0, stream, nodes, sp, chunkOwner, bins[0], chunkCnt);
             hipLaunchKernelGGL(k_chunk_scan, dim3(h.large), dim3(PTB_BLOCK), 0, stream, nodes, sp, largeRank, chunkCnt);
             hipLaunchKernelGGL(k_chunk_scatter, dim3(h.chunks), dim3(PTB_BLOCK), 0, stream, nodes, sp, chunkOwner, bins[0], chunkCnt, order[0], order[1]);
@@ -537,6 +734,14 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
         levelStart.push_back(h.nodes);
         nActive = h.next_active;
         act ^= 1;
+    }
+    // everything below the small nodes, one thread per subtree; their nodes follow the levels' in creation order
+    levelNodes = h.nodes;
+    if (h.small > 0) {
+        hipLaunchKernelGGL(k_small_subtrees, dim3((h.small + 63u) / 64u), dim3(64), 0, stream, nodes, small, h.small, cent, pmin, pmax, order[0], order[1], bins[0], ctr);
+        PTB_TRY(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
+        PTB_TRY(hipStreamSynchronize(stream));
+        smallDepth = h.max_level + 1u;
     }
     // renumber: nodes below (deepest level first), then final indices (root first)
     for (size_t l = levelStart.size() - 1; l-- > 0;) {
@@ -547,6 +752,7 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
         const uint32_t lo = levelStart[l], hi = levelStart[l + 1];
         if (hi > lo) hipLaunchKernelGGL(k_number, dim3(grid(hi - lo)), dim3(PTB_BLOCK), 0, stream, nodes, lo, hi);
     }
+    if (h.nodes > levelNodes) hipLaunchKernelGGL(k_small_finish, dim3(grid(h.nodes - levelNodes)), dim3(PTB_BLOCK), 0, stream, nodes, levelNodes, h.nodes);
     hipLaunchKernelGGL(k_emit, dim3(grid(h.nodes)), dim3(PTB_BLOCK), 0, stream, nodes, h.nodes, d_nodes_out);
     if (n) hipLaunchKernelGGL(k_gather, dim3(grid(n * 7u)), dim3(PTB_BLOCK), 0, stream, d_tris, order[cur], n, d_tris_out);
     PTB_TRY(hipGetLastError());
@@ -555,13 +761,13 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     if (levels_out) {   // levels that hold nodes: the last round of the loop adds an empty one when none of its nodes split
         uint32_t levels = 0;
         for (size_t l = 0; l + 1 < levelStart.size(); l++) levels += levelStart[l + 1] > levelStart[l] ? 1u : 0u;
-        *levels_out = levels;
+        *levels_out = levels > smallDepth ? levels : smallDepth;
     }
     if (keep_nodes) { *keep_nodes = nodes; nodes = nullptr; }
 done:
     (void)hipFree(pmin); (void)hipFree(pmax); (void)hipFree(cent);
     for (int k = 0; k < 2; k++) { (void)hipFree(order[k]); (void)hipFree(bins[k]); (void)hipFree(active[k]); }
-    (void)hipFree(largeRank); (void)hipFree(chunkOwner); (void)hipFree(chunkCnt);
+    (void)hipFree(largeRank); (void)hipFree(chunkOwner); (void)hipFree(chunkCnt); (void)hipFree(small);
     (void)hipFree(seg); (void)hipFree(sortb); (void)hipFree(sorte); (void)hipFree(rootk); (void)hipFree(nodes); (void)hipFree(sp); (void)hipFree(ctr); (void)hipFree(tmp);
     return err;
 #undef PTB_TRY
