@@ -37,7 +37,7 @@ namespace ptbuild {
 #define PTB_BINS 8             // Accelerator.cs:12
 #define PTB_CHUNK 2048         // primitives per block of the chunked partition; nodes at least this large take it
 #ifndef PTB_SMALL
-#define PTB_SMALL 64           // nodes of at most this many primitives are finished by one thread each
+#define PTB_SMALL 32           // nodes of at most this many primitives are finished by one thread each
 #endif
 #define PTB_COPIES 16          // private copies of a block's bin table in LDS (lane & 15 picks one): a sixteenth of the conflicts
 
@@ -247,12 +247,16 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_split_bins(uint32_t n_active, Spl
     }
 }
 
-// Accelerator.cs:215-227: bin of every primitive, bin counts and domains.  Tiles and the LDS table of the current tile's first
-// node as in k_centroid_range; the table is kept PTB_COPIES times so that the 256 threads do not all queue on the same eight
-// counters.
+// Accelerator.cs:215-227: bin of every primitive, bin counts and domains, gathered in LDS before they go to the nodes' global
+// counters.  A node's positions are consecutive, so a tile of 256 positions whose first and last position carry the same node
+// lies inside it: such tiles (all of them near the top of the tree) add to one table that the block carries from tile to tile,
+// kept PTB_COPIES times so that 256 threads do not queue on the same eight counters, and written out when the node changes.
+// Any other tile numbers the runs of equal nodes it contains (at most PTB_COPIES of them get a table entry each; a node further
+// on in a tile of tiny nodes falls back to global atomics) and writes its entries out when it ends.
 __global__ void __launch_bounds__(PTB_BLOCK) k_bin(const float4* cent, const float4* pmin, const float4* pmax, const uint32_t* order, const uint32_t* seg,
                                                    uint32_t n, Split* sp, uint8_t* bin_of, uint32_t tiles) {
-    __shared__ uint32_t s_cnt[PTB_COPIES][PTB_BINS], s_mn[PTB_COPIES][PTB_BINS][3], s_mx[PTB_COPIES][PTB_BINS][3], s_rank;
+    __shared__ uint32_t s_cnt[PTB_COPIES][PTB_BINS], s_mn[PTB_COPIES][PTB_BINS][3], s_mx[PTB_COPIES][PTB_BINS][3];
+    __shared__ uint32_t s_entryRank[PTB_COPIES], s_waveRuns[PTB_BLOCK / 64];
     auto clearTable = [&]() {
         for (uint32_t t = threadIdx.x; t < PTB_COPIES * PTB_BINS; t += PTB_BLOCK) {
             const uint32_t c = t / PTB_BINS, j = t % PTB_BINS;
@@ -260,8 +264,8 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_bin(const float4* cent, const flo
             for (int a = 0; a < 3; a++) { s_mn[c][j][a] = PTB_KEY_POS_INF; s_mx[c][j][a] = PTB_KEY_NEG_INF; }
         }
     };
-    auto flushTable = [&]() {   // all threads call it between barriers
-        if (threadIdx.x < PTB_BINS && s_rank != PTB_NONE) {
+    auto flushCarried = [&](uint32_t rank) {   // the PTB_COPIES entries are copies of one node's table
+        if (threadIdx.x < PTB_BINS) {
             const int j = threadIdx.x;
             uint32_t cnt = 0, mn[3] = {PTB_KEY_POS_INF, PTB_KEY_POS_INF, PTB_KEY_POS_INF}, mx[3] = {PTB_KEY_NEG_INF, PTB_KEY_NEG_INF, PTB_KEY_NEG_INF};
             for (int c = 0; c < PTB_COPIES; c++) {
@@ -269,29 +273,55 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_bin(const float4* cent, const flo
                 for (int a = 0; a < 3; a++) { mn[a] = s_mn[c][j][a] < mn[a] ? s_mn[c][j][a] : mn[a]; mx[a] = s_mx[c][j][a] > mx[a] ? s_mx[c][j][a] : mx[a]; }
             }
             if (cnt != 0) {
-                Split& g = sp[s_rank];
+                Split& g = sp[rank];
                 atomicAdd(&g.cnt[j], cnt);
                 for (int a = 0; a < 3; a++) { atomicMin(&g.bmn[j][a], mn[a]); atomicMax(&g.bmx[j][a], mx[a]); }
             }
         }
     };
+    auto flushRuns = [&]() {                   // entry e is the table of the tile's e-th run
+        if (threadIdx.x < PTB_COPIES * PTB_BINS) {
+            const uint32_t e = threadIdx.x / PTB_BINS, j = threadIdx.x % PTB_BINS;
+            const uint32_t cnt = s_cnt[e][j];
+            if (cnt != 0) {
+                Split& g = sp[s_entryRank[e]];
+                atomicAdd(&g.cnt[j], cnt);
+                for (int a = 0; a < 3; a++) { atomicMin(&g.bmn[j][a], s_mn[e][j][a]); atomicMax(&g.bmx[j][a], s_mx[e][j][a]); }
+            }
+        }
+    };
     clearTable();
-    if (threadIdx.x == 0) s_rank = PTB_NONE;
+    uint32_t carried = PTB_NONE;   // block-uniform: the node whose table the block is carrying
     __syncthreads();
     for (uint32_t tile = 0; tile < tiles; tile++) {
         const uint32_t base = (blockIdx.x * tiles + tile) * PTB_BLOCK;
         if (base >= n) break;
+        const uint32_t lastPos = base + PTB_BLOCK - 1u < n ? base + PTB_BLOCK - 1u : n - 1u;
         const uint32_t rank0 = seg[base];
-        if (rank0 != s_rank) {            // block-uniform
+        const bool inside = rank0 != PTB_NONE && seg[lastPos] == rank0;   // block-uniform
+        if (carried != PTB_NONE && !(inside && rank0 == carried)) {
             __syncthreads();
-            flushTable();
+            flushCarried(carried);
             __syncthreads();
             clearTable();
-            if (threadIdx.x == 0) s_rank = rank0;
             __syncthreads();
+            carried = PTB_NONE;
         }
         const uint32_t i = base + threadIdx.x;
         const uint32_t r = i < n ? seg[i] : PTB_NONE;
+        uint32_t entry = threadIdx.x & (PTB_COPIES - 1u);
+        if (inside) {
+            carried = rank0;
+        } else {
+            const bool starts = threadIdx.x == 0u || r != (i - 1u < n ? seg[i - 1u] : PTB_NONE);
+            const unsigned long long m = __ballot(starts);
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            if (lane == 0u) s_waveRuns[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            entry = (uint32_t)__popcll(m & ((2ull << lane) - 1ull)) - 1u;
+            for (uint32_t w = 0; w < wave; w++) entry += s_waveRuns[w];
+            if (starts && entry < PTB_COPIES) s_entryRank[entry] = r;
+        }
         if (r != PTB_NONE && sp[r].usable) {
             const Split& s = sp[r];
             const uint32_t id = order[i];
@@ -302,19 +332,25 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_bin(const float4* cent, const flo
             bin_of[i] = (uint8_t)j;
             const float4 lo = pmin[id], hi = pmax[id];
             const uint32_t klo[3] = {fkey(lo.x), fkey(lo.y), fkey(lo.z)}, khi[3] = {fkey(hi.x), fkey(hi.y), fkey(hi.z)};
-            if (r == rank0) {
-                const uint32_t cp = threadIdx.x & (PTB_COPIES - 1u);
-                atomicAdd(&s_cnt[cp][j], 1u);
-                for (int a = 0; a < 3; a++) { atomicMin(&s_mn[cp][j][a], klo[a]); atomicMax(&s_mx[cp][j][a], khi[a]); }
+            if (entry < PTB_COPIES) {
+                atomicAdd(&s_cnt[entry][j], 1u);
+                for (int a = 0; a < 3; a++) { atomicMin(&s_mn[entry][j][a], klo[a]); atomicMax(&s_mx[entry][j][a], khi[a]); }
             } else {
                 Split& g = sp[r];
                 atomicAdd(&g.cnt[j], 1u);
                 for (int a = 0; a < 3; a++) { atomicMin(&g.bmn[j][a], klo[a]); atomicMax(&g.bmx[j][a], khi[a]); }
             }
         }
+        if (!inside) {
+            __syncthreads();
+            flushRuns();
+            __syncthreads();
+            clearTable();
+            __syncthreads();
+        }
     }
     __syncthreads();
-    flushTable();
+    if (carried != PTB_NONE) flushCarried(carried);
 }
 
 // Box.Union(a, b) with a = a bin's domain, b = the running box (Box.cs:81-88)
