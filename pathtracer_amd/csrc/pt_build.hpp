@@ -37,7 +37,7 @@ namespace ptbuild {
 #define PTB_BINS 8             // Accelerator.cs:12
 #define PTB_CHUNK 2048         // primitives per block of the chunked partition; nodes at least this large take it
 #ifndef PTB_SMALL
-#define PTB_SMALL 32           // nodes of at most this many primitives are finished by one thread each
+#define PTB_SMALL 64           // nodes of at most this many primitives are finished by one thread each
 #endif
 #define PTB_COPIES 16          // private copies of a block's bin table in LDS (lane & 15 picks one): a sixteenth of the conflicts
 
@@ -539,98 +539,218 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_reassign(const BNode* nodes, cons
     seg[i] = next;
 }
 
-// ---- small subtrees: Accelerator.Subdivide (Accelerator.cs:136-177) with Parition (:188-280) on one thread per subtree.
-// order[first, first + count) of the subtree's root belongs to this thread alone (tmp and bin_of at the same positions are its
-// scratch).  Nodes are taken from the shared counter two at a time; visiting left before right, as the recursion does, makes the
-// k-th pair this thread allocates the pair at relative index 2k of the reference's numbering of the subtree, so `index` (of the
-// node) and `block` (of its children pair) are written as relative numbers and k_small_finish adds the root's base later.
-__global__ void __launch_bounds__(64) k_small_subtrees(BNode* nodes, const uint32_t* small, uint32_t n_small, const float4* cent, const float4* pmin,
-                                                       const float4* pmax, uint32_t* order, uint32_t* tmp, uint8_t* bin_of, Counters* ctr) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_small) return;
-    const uint32_t root = small[t];
+// ---- small subtrees: Accelerator.Subdivide (Accelerator.cs:136-177) with Parition (:188-280), one wave per subtree.
+// Lane k holds the primitive at position first + k of the subtree's root; the wave works on all nodes of one depth at a time.
+// The primitives of a node are consecutive lanes, so everything the reference folds over a node's list is a scan over a lane
+// range: the centroid range; after the lanes of a node have been put in bin order (the reference's partition, stable inside a
+// bin), the boxes left and right of a split plane are a prefix and a suffix union, and the planes worth looking at are the
+// boundaries between two occupied bins (a plane next to an empty bin repeats its neighbour's cost, which the reference's strict
+// "<" ignores; a plane with an empty side costs 0 * inf = NaN, which it ignores too).  A node that stays a leaf keeps its
+// primitives in the order they had (Accelerator.cs:262 returns before the rewrite).
+// The subtree takes shape in LDS with local node numbers (the root 0, then two per split node, depth by depth).  When it is
+// complete it is numbered the way the recursion would have (pair, everything below the left node, everything below the right
+// one) relative to the root's pair (k_small_finish adds the root's base later), the waves of a block take their nodes from the
+// shared counter with one atomic between them — a returning atomic on one address is served every dozen nanoseconds, which
+// at one per wave and depth was most of this kernel's time — and every wave writes its finished nodes out.
+__device__ inline uint32_t segMinU(uint32_t v, uint32_t lane, uint32_t lo, uint32_t hi) {
+    for (uint32_t off = 1; off < 64u; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, off); if (lane >= lo + off) v = t < v ? t : v; }
+    return (uint32_t)__shfl((int)v, (int)hi - 1);
+}
+__device__ inline uint32_t segMaxU(uint32_t v, uint32_t lane, uint32_t lo, uint32_t hi) {
+    for (uint32_t off = 1; off < 64u; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, off); if (lane >= lo + off) v = t > v ? t : v; }
+    return (uint32_t)__shfl((int)v, (int)hi - 1);
+}
+#define PTB_SW_WAVES 8     // subtrees (waves) per block of k_small_subtrees
+__global__ void __launch_bounds__(PTB_SW_WAVES * 64) k_small_subtrees(BNode* nodes, const uint32_t* small, uint32_t n_small, const float4* cent,
+                                                                      const float4* pmin, const float4* pmax, uint32_t* order, Counters* ctr) {
+    static_assert(PTB_SMALL <= 64, "one lane per primitive of a small subtree");
+    constexpr int WAVES = PTB_SW_WAVES, LOCAL = 128;   // at most 2 * 64 - 1 nodes
+    __shared__ float s_box[WAVES][LOCAL][6];
+    __shared__ uint8_t s_first[WAVES][LOCAL], s_count[WAVES][LOCAL], s_axis[WAVES][LOCAL], s_depth[WAVES][LOCAL];
+    __shared__ uint8_t s_left[WAVES][LOCAL];           // local number of the left child (right = left + 1), 0xFF for a leaf
+    __shared__ uint8_t s_below[WAVES][LOCAL], s_block[WAVES][LOCAL], s_index[WAVES][LOCAL];
+    __shared__ uint8_t s_levelStart[WAVES][68];        // local numbers are handed out depth by depth
+    __shared__ uint8_t s_src[WAVES][64];
+    __shared__ uint32_t s_made[WAVES], s_base;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * WAVES + wave;
+    const bool live = t < n_small;                     // wave-uniform
+    auto waveSync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     const float inf = __builtin_huge_valf();
-    int32_t stack[PTB_SMALL];
-    int sp = 0;
-    uint32_t pairs = 0, maxLevel = nodes[root].level;
-    stack[sp++] = (int32_t)root;
-    while (sp > 0) {
-        const int32_t idx = stack[--sp];
-        const BNode nd = nodes[idx];
-        if (nd.count < PTB_LEAF) continue;                                   // Accelerator.cs:140-143
-        const int axis = domainOf(nd.mn, nd.mx);
-        const int first = nd.first, count = nd.count;
-        float cmin = inf, cmax = -inf;                                       // CentroidBounds, Accelerator.cs:294-310
-        for (int i = first; i < first + count; i++) {
-            const float c = axisOf(cent[order[i]], axis);
-            cmin = c < cmin ? c : cmin;
-            cmax = c > cmax ? c : cmax;
+    uint32_t root = 0, total = 0, rootLevel = 0, localCount = 1, depth = 0, id = 0;
+    int32_t f0 = 0;
+    bool holds = false;
+    if (live) {
+        root = small[t];
+        f0 = nodes[root].first;
+        total = (uint32_t)nodes[root].count;
+        rootLevel = nodes[root].level;
+        // the lane's primitive
+        holds = lane < total;
+        id = holds ? order[f0 + lane] : 0u;
+        float c[3] = {0, 0, 0}, lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+        if (holds) {
+            const float4 cc = cent[id], l4 = pmin[id], h4 = pmax[id];
+            c[0] = cc.x; c[1] = cc.y; c[2] = cc.z;
+            lo[0] = l4.x; lo[1] = l4.y; lo[2] = l4.z;
+            hi[0] = h4.x; hi[1] = h4.y; hi[2] = h4.z;
         }
-        const float k0 = cmin, l = cmax - k0;
-        if (l < PTB_EPSILON) continue;                                       // Accelerator.cs:203-204
-        const float k1 = ((float)PTB_BINS - PTB_EPSILON) / l;
-        int cnt[PTB_BINS];
-        float bmn[PTB_BINS][3], bmx[PTB_BINS][3];
-        for (int j = 0; j < PTB_BINS; j++) { cnt[j] = 0; for (int a = 0; a < 3; a++) { bmn[j][a] = inf; bmx[j][a] = -inf; } }
-        for (int i = first; i < first + count; i++) {                        // Accelerator.cs:215-227
-            const uint32_t id = order[i];
-            const float b = (axisOf(cent[id], axis) - k0) * k1;
-            int j = (int)b;
+        // the node the lane's primitive is in
+        bool active = holds;                              // false once its node is a leaf
+        uint32_t nlo = holds ? 0u : lane, nhi = holds ? total : lane + 1u;
+        float nmn[3], nmx[3];
+        for (int a = 0; a < 3; a++) { nmn[a] = nodes[root].mn[a]; nmx[a] = nodes[root].mx[a]; }
+        uint32_t myLocal = 0;
+        if (lane == 0) { s_left[wave][0] = 0xFFu; s_levelStart[wave][0] = 0; s_levelStart[wave][1] = 1; }
+
+        while (__any(active)) {
+            const int axis = domainOf(nmn, nmx);
+            const float ca = axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]);
+            // CentroidBounds along the axis (Accelerator.cs:294-310), k0 and k1 (:196-213)
+            const uint32_t kc = fkey(ca);
+            const float k0 = fval(segMinU(kc, lane, nlo, nhi));
+            const float l = fval(segMaxU(kc, lane, nlo, nhi)) - k0;
+            const bool usable = active && !(l < PTB_EPSILON);
+            const float k1 = ((float)PTB_BINS - PTB_EPSILON) / l;
+            int j = usable ? (int)((ca - k0) * k1) : 0;
             j = j < 0 ? 0 : (j > PTB_BINS - 1 ? PTB_BINS - 1 : j);
-            bin_of[i] = (uint8_t)j;
-            cnt[j]++;
-            const float4 lo = pmin[id], hi = pmax[id];
-            bmx[j][0] = hi.x > bmx[j][0] ? hi.x : bmx[j][0]; bmx[j][1] = hi.y > bmx[j][1] ? hi.y : bmx[j][1]; bmx[j][2] = hi.z > bmx[j][2] ? hi.z : bmx[j][2];
-            bmn[j][0] = lo.x < bmn[j][0] ? lo.x : bmn[j][0]; bmn[j][1] = lo.y < bmn[j][1] ? lo.y : bmn[j][1]; bmn[j][2] = lo.z < bmn[j][2] ? lo.z : bmn[j][2];
+            // position of the primitive once its node is in bin order
+            const unsigned long long nodeMask = (nhi >= 64u ? ~0ull : (1ull << nhi) - 1ull) & ~((1ull << nlo) - 1ull);
+            const unsigned long long before = nodeMask & ((1ull << lane) - 1ull);
+            uint32_t pos = 0;
+            for (int b = 0; b < PTB_BINS; b++) {
+                const unsigned long long m = __ballot(usable && j == b);
+                if (b < j) pos += (uint32_t)__popcll(m & nodeMask);
+                else if (b == j) pos += (uint32_t)__popcll(m & before);
+            }
+            const uint32_t newLane = usable ? nlo + pos : lane;
+            s_src[wave][newLane] = (uint8_t)lane;
+            waveSync();
+            const int src = (int)s_src[wave][lane];
+            waveSync();
+            const uint32_t pid = (uint32_t)__shfl((int)id, src);
+            const int pj = __shfl(j, src);
+            float pc[3], plo[3], phi[3];
+            for (int a = 0; a < 3; a++) { pc[a] = __shfl(c[a], src); plo[a] = __shfl(lo[a], src); phi[a] = __shfl(hi[a], src); }
+            // union of the node's primitives up to this lane, and from this lane on
+            float pmn[3], pmx[3], smn[3], smx[3];
+            for (int a = 0; a < 3; a++) { pmn[a] = smn[a] = plo[a]; pmx[a] = smx[a] = phi[a]; }
+            for (uint32_t off = 1; off < 64u; off <<= 1) {
+                const bool up = lane >= nlo + off, down = lane + off < nhi;
+                for (int a = 0; a < 3; a++) {
+                    const float u0 = __shfl_up(pmn[a], off), u1 = __shfl_up(pmx[a], off), d0 = __shfl_down(smn[a], off), d1 = __shfl_down(smx[a], off);
+                    if (up) { pmn[a] = u0 < pmn[a] ? u0 : pmn[a]; pmx[a] = u1 > pmx[a] ? u1 : pmx[a]; }
+                    if (down) { smn[a] = d0 < smn[a] ? d0 : smn[a]; smx[a] = d1 > smx[a] ? d1 : smx[a]; }
+                }
+            }
+            // the sweep (Accelerator.cs:229-262): a split after this lane, if the next lane starts another bin
+            const int nextJ = __shfl_down(pj, 1);
+            float rmn[3], rmx[3];
+            for (int a = 0; a < 3; a++) { rmn[a] = __shfl_down(smn[a], 1); rmx[a] = __shfl_down(smx[a], 1); }
+            const uint32_t count = nhi - nlo, ln = lane + 1u - nlo, rn = count - ln;
+            const float cost0 = areaOf(nmn, nmx) * (float)count;
+            const float cost = (float)ln * areaOf(pmn, pmx) + (float)rn * areaOf(rmn, rmx);
+            const bool better = usable && lane + 1u < nhi && pj != nextJ && cost < cost0;
+            // smallest cost, then the first plane that reaches it
+            uint32_t bc = better ? __float_as_uint(cost) : 0xFFFFFFFFu, bl = better ? lane : 0xFFFFFFFFu;
+            for (uint32_t off = 1; off < 64u; off <<= 1) {
+                const uint32_t tc = (uint32_t)__shfl_up((int)bc, off), tl = (uint32_t)__shfl_up((int)bl, off);
+                if (lane >= nlo + off && (tc < bc || (tc == bc && tl < bl))) { bc = tc; bl = tl; }
+            }
+            const uint32_t splitLane = (uint32_t)__shfl((int)bl, (int)nhi - 1);
+            const bool split = usable && splitLane != 0xFFFFFFFFu;
+            // the children's bounds (Accelerator.cs:264-279): what lies left and right of the chosen plane
+            const int sl = split ? (int)splitLane : (int)lane, sr = split ? (int)splitLane + 1 : (int)lane;
+            float Lmn[3], Lmx[3], Rmn[3], Rmx[3];
+            for (int a = 0; a < 3; a++) { Lmn[a] = __shfl(pmn[a], sl); Lmx[a] = __shfl(pmx[a], sl); Rmn[a] = __shfl(smn[a], sr); Rmx[a] = __shfl(smx[a], sr); }
+            // two new nodes per split node
+            const bool starts = split && lane == nlo;
+            const unsigned long long sm = __ballot(starts);
+            const uint32_t nSplit = (uint32_t)__popcll(sm);
+            if (nSplit == 0u) break;
+            const uint32_t childLocal = localCount + 2u * (uint32_t)__popcll(sm & ((1ull << nlo) - 1ull));
+            if (starts) { s_left[wave][myLocal] = (uint8_t)childLocal; s_axis[wave][myLocal] = (uint8_t)axis; }
+            depth++;
+            active = false;
+            if (split) {
+                id = pid;
+                for (int a = 0; a < 3; a++) { c[a] = pc[a]; lo[a] = plo[a]; hi[a] = phi[a]; }
+                const bool right = lane > splitLane;
+                if (right) nlo = splitLane + 1u; else nhi = splitLane + 1u;
+                for (int a = 0; a < 3; a++) { nmn[a] = right ? Rmn[a] : Lmn[a]; nmx[a] = right ? Rmx[a] : Lmx[a]; }
+                myLocal = childLocal + (right ? 1u : 0u);
+                if (lane == nlo) {
+                    for (int a = 0; a < 3; a++) { s_box[wave][myLocal][a] = nmn[a]; s_box[wave][myLocal][3 + a] = nmx[a]; }
+                    s_first[wave][myLocal] = (uint8_t)nlo;
+                    s_count[wave][myLocal] = (uint8_t)(nhi - nlo);
+                    s_depth[wave][myLocal] = (uint8_t)depth;
+                    s_left[wave][myLocal] = 0xFFu;
+                }
+                active = nhi - nlo >= PTB_LEAF;           // Accelerator.cs:140-143
+            }
+            localCount += 2u * nSplit;
+            if (lane == 0) s_levelStart[wave][depth + 1u] = (uint8_t)localCount;
         }
-        int best = -1, bestPlane = 0;                                        // the sweep, Accelerator.cs:229-262
-        float cost = areaOf(nd.mn, nd.mx) * (float)count;
-        int ln = 0, rn = count;
-        float lmn[3] = {inf, inf, inf}, lmx[3] = {-inf, -inf, -inf};
-        for (int i = 1; i < PTB_BINS; i++) {
-            ln += cnt[i - 1];
-            rn -= cnt[i - 1];
-            for (int a = 0; a < 3; a++) { lmx[a] = bmx[i - 1][a] > lmx[a] ? bmx[i - 1][a] : lmx[a]; lmn[a] = bmn[i - 1][a] < lmn[a] ? bmn[i - 1][a] : lmn[a]; }
-            float rmn[3] = {inf, inf, inf}, rmx[3] = {-inf, -inf, -inf};
-            for (int j = i; j < PTB_BINS; j++)
-                for (int a = 0; a < 3; a++) { rmx[a] = bmx[j][a] > rmx[a] ? bmx[j][a] : rmx[a]; rmn[a] = bmn[j][a] < rmn[a] ? bmn[j][a] : rmn[a]; }
-            const float c = (float)ln * areaOf(lmn, lmx) + (float)rn * areaOf(rmn, rmx);
-            if (c < cost) { best = ln; bestPlane = i; cost = c; }
+        waveSync();
+        // nodes below every node, deepest nodes first; then the reference's numbers, root first
+        for (uint32_t d = depth + 1u; d-- > 0u;) {
+            const uint32_t n = s_levelStart[wave][d] + lane;
+            if (n < s_levelStart[wave][d + 1u]) {
+                const uint32_t left = s_left[wave][n];
+                s_below[wave][n] = left == 0xFFu ? (uint8_t)0 : (uint8_t)(2u + s_below[wave][left] + s_below[wave][left + 1u]);
+            }
+            waveSync();
         }
-        if (best < 0) continue;                                              // Accelerator.cs:262: stays a leaf
-        // the reference rewrites the range bin by bin, order kept inside a bin (Accelerator.cs:264-279)
-        int offset[PTB_BINS];
-        for (int j = 0, acc = 0; j < PTB_BINS; j++) { offset[j] = acc; acc += cnt[j]; }
-        for (int i = first; i < first + count; i++) tmp[first + offset[bin_of[i]]++] = order[i];
-        for (int i = first; i < first + count; i++) order[i] = tmp[i];
-        BNode L{}, R{};
-        for (int a = 0; a < 3; a++) { L.mn[a] = inf; L.mx[a] = -inf; R.mn[a] = inf; R.mx[a] = -inf; }
-        for (int j = 0; j < PTB_BINS; j++) {
-            if (cnt[j] == 0) continue;
-            BNode& side = j < bestPlane ? L : R;
-            for (int a = 0; a < 3; a++) { side.mx[a] = bmx[j][a] > side.mx[a] ? bmx[j][a] : side.mx[a]; side.mn[a] = bmn[j][a] < side.mn[a] ? bmn[j][a] : side.mn[a]; }
+        if (lane == 0) s_block[wave][0] = 0u;
+        waveSync();
+        for (uint32_t d = 0; d <= depth; d++) {
+            const uint32_t n = s_levelStart[wave][d] + lane;
+            if (n < s_levelStart[wave][d + 1u]) {
+                const uint32_t left = s_left[wave][n];
+                if (left != 0xFFu) {
+                    const uint32_t blk = s_block[wave][n];
+                    s_index[wave][left] = (uint8_t)blk;
+                    s_index[wave][left + 1u] = (uint8_t)(blk + 1u);
+                    s_block[wave][left] = (uint8_t)(blk + 2u);
+                    s_block[wave][left + 1u] = (uint8_t)(blk + 2u + s_below[wave][left]);
+                }
+            }
+            waveSync();
         }
-        L.first = first; L.count = best;
-        R.first = first + best; R.count = count - best;
-        L.left = R.left = -1;
-        L.level = R.level = nd.level + 1u;
-        maxLevel = L.level > maxLevel ? L.level : maxLevel;
-        L.next_rank = R.next_rank = PTB_NONE;
-        L.aux = R.aux = root;
-        L.index = 2u * pairs;
-        R.index = 2u * pairs + 1u;
-        const uint32_t at = atomicAdd(&ctr->nodes, 2u);
-        nodes[at] = L;
-        nodes[at + 1] = R;
-        nodes[idx].left = (int32_t)at;
-        nodes[idx].axis = axis;
-        if ((uint32_t)idx != root) nodes[idx].block = 2u * pairs;            // the root's own pair number comes from the levels above it
-        pairs++;
-        stack[sp++] = (int32_t)at + 1;                                       // left is subdivided first (Accelerator.cs:174-175)
-        stack[sp++] = (int32_t)at;
+        if (holds) order[f0 + lane] = id;
     }
-    nodes[root].below = 2u * pairs;
-    atomicMax(&ctr->max_level, maxLevel);
+    // this block's nodes: one atomic for all its subtrees
+    if (lane == 0) s_made[wave] = live ? localCount - 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (int w = 0; w < WAVES; w++) { const uint32_t m = s_made[w]; s_made[w] = sum; sum += m; }
+        s_base = sum ? atomicAdd(&ctr->nodes, sum) : 0u;
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint32_t base = s_base + s_made[wave] - 1u;     // local node k >= 1 becomes node base + k
+    for (uint32_t k = 1u + lane; k < localCount; k += 64u) {
+        BNode nd{};
+        for (int a = 0; a < 3; a++) { nd.mn[a] = s_box[wave][k][a]; nd.mx[a] = s_box[wave][k][3 + a]; }
+        nd.first = f0 + (int32_t)s_first[wave][k];
+        nd.count = (int32_t)s_count[wave][k];
+        const uint32_t left = s_left[wave][k];
+        nd.left = left == 0xFFu ? -1 : (int32_t)(base + left);
+        nd.axis = left == 0xFFu ? 0 : (int32_t)s_axis[wave][k];
+        nd.next_rank = PTB_NONE;
+        nd.block = left == 0xFFu ? 0u : (uint32_t)s_block[wave][k];
+        nd.index = s_index[wave][k];
+        nd.level = rootLevel + s_depth[wave][k];
+        nd.aux = root;
+        nodes[base + k] = nd;
+    }
+    if (lane == 0) {
+        const uint32_t left = s_left[wave][0];
+        if (left != 0xFFu) { nodes[root].left = (int32_t)(base + left); nodes[root].axis = (int32_t)s_axis[wave][0]; }
+        nodes[root].below = s_below[wave][0];
+        atomicMax(&ctr->max_level, rootLevel + depth);
+    }
 }
 // relative numbers of the thread-built nodes -> final ones, once the levels above have numbered the subtree roots
 __global__ void __launch_bounds__(PTB_BLOCK) k_small_finish(BNode* nodes, uint32_t lo, uint32_t hi) {
@@ -774,7 +894,7 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     // everything below the small nodes, one thread per subtree; their nodes follow the levels' in creation order
     levelNodes = h.nodes;
     if (h.small > 0) {
-        hipLaunchKernelGGL(k_small_subtrees, dim3((h.small + 63u) / 64u), dim3(64), 0, stream, nodes, small, h.small, cent, pmin, pmax, order[0], order[1], bins[0], ctr);
+        hipLaunchKernelGGL(k_small_subtrees, dim3((h.small + PTB_SW_WAVES - 1u) / PTB_SW_WAVES), dim3(PTB_SW_WAVES * 64), 0, stream, nodes, small, h.small, cent, pmin, pmax, order[0], ctr);
         PTB_TRY(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
         PTB_TRY(hipStreamSynchronize(stream));
         smallDepth = h.max_level + 1u;
