@@ -1210,20 +1210,23 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     const uint32_t n = (uint32_t)n_tri;
+    ptbuild::BNode root{};   // destination of a queued copy: declared before `w`, whose destructor waits for the stream
     // Everything is built into buffers of this call; the context's scene is replaced only when all of it exists, and
     // the destructor releases whatever is still held on any way out (error returns and exceptions alike).
     struct Work {
         pt_ctx* c;
-        ptbuild::Tri112 *d_in = nullptr, *d_sorted = nullptr, *d_lightTris = nullptr;
+        ptbuild::Tri112 *d_in = nullptr, *d_sorted = nullptr;
         ptbuild::Node32* d_nodes = nullptr;
         ptbuild::BNode* bn = nullptr;
         uint32_t *d_flagA = nullptr, *d_idxA = nullptr, *d_flagB = nullptr, *d_idxB = nullptr, *d_bad = nullptr;
         void* tmp = nullptr;
         void *pairs = nullptr, *quads = nullptr, *big = nullptr, *hot = nullptr, *cold = nullptr, *mats = nullptr, *lights = nullptr;   // the new scene
         hipEvent_t ea = nullptr, eb = nullptr;
+        float lightSum = 0.0f;   // written by a copy queued on the stream
         explicit Work(pt_ctx* ctx) : c(ctx) {}
         ~Work() {
-            void* all[] = {d_in, d_sorted, d_lightTris, d_nodes, bn, d_flagA, d_idxA, d_flagB, d_idxB, d_bad, tmp, pairs, quads, big, hot, cold, mats, lights};
+            if (c->stream) (void)hipStreamSynchronize(c->stream);   // nothing queued may outlive the buffers (or this object)
+            void* all[] = {d_in, d_sorted, d_nodes, bn, d_flagA, d_idxA, d_flagB, d_idxB, d_bad, tmp, pairs, quads, big, hot, cold, mats, lights};
             for (void* p : all) if (p) (void)hipFree(p);
             if (ea) c->pool.push_back(ea);
             if (eb) c->pool.push_back(eb);
@@ -1258,8 +1261,7 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
         TRY(hipMemcpyAsync(w.mats, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, c->stream));
     }
     // ---- triangles: hot / cold records, the light table
-    std::vector<float4> lights;
-    float lightSum = 0.0f;
+    uint32_t nLights = 0;
     if (n) {
         TRY(hipMalloc(&w.hot, (size_t)n * 48));
         TRY(hipMalloc(&w.cold, (size_t)n * 48));
@@ -1272,16 +1274,14 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
         TRY(hipMemcpyAsync(&bad, w.d_bad, 4, hipMemcpyDeviceToHost, c->stream));
         TRY(hipStreamSynchronize(c->stream));
         if (bad) FAIL(c, PT_E_INVALID_ARG, "a triangle has a material index outside [0, %d)", n_mat);
-        const uint32_t nLights = lastFlag + lastIdx;
+        nLights = lastFlag + lastIdx;
         if (nLights) {
-            TRY(hipMalloc((void**)&w.d_lightTris, (size_t)nLights * 112));
-            hipLaunchKernelGGL(ptrepack::k_collect_lights, dim3(launchGrid(n)), dim3(256), 0, c->stream, w.d_sorted, n, w.d_flagA, w.d_idxA, w.d_lightTris);
-            std::vector<HostTriangle> lt(nLights);
-            TRY(hipMemcpyAsync(lt.data(), w.d_lightTris, (size_t)nLights * 112, hipMemcpyDeviceToHost, c->stream));
-            TRY(hipStreamSynchronize(c->stream));
-            for (const HostTriangle& t : lt) appendLight(t, lights, lightSum);   // triangle order: the running sum rounds as on the CPU path
-            TRY(hipMalloc(&w.lights, lights.size() * sizeof(float4)));
-            TRY(hipMemcpyAsync(w.lights, lights.data(), lights.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+            // rows in triangle order; the running sum rounds as on the CPU path (d_bad is free again: it receives the total)
+            TRY(hipMalloc(&w.lights, (size_t)nLights * 3 * sizeof(float4)));
+            float* const areas = (float*)w.d_flagB;   // free until the node flags are formed
+            hipLaunchKernelGGL(ptrepack::k_light_rows, dim3(launchGrid(n)), dim3(256), 0, c->stream, w.d_sorted, n, w.d_flagA, w.d_idxA, (float4*)w.lights, areas);
+            hipLaunchKernelGGL(ptrepack::k_light_sums, dim3(1), dim3(64), 0, c->stream, areas, (float4*)w.lights, nLights, (float*)w.d_bad);
+            TRY(hipMemcpyAsync(&w.lightSum, w.d_bad, 4, hipMemcpyDeviceToHost, c->stream));   // read after the final synchronisation
         }
     }
     // ---- nodes: pair records, quad records, big-leaf rows
@@ -1305,7 +1305,6 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
         hipLaunchKernelGGL(ptrepack::k_records, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_idxA, w.d_idxB, w.d_flagB, (float4*)w.pairs,
                            (float4*)w.quads, (uint2*)w.big);
     }
-    ptbuild::BNode root;
     TRY(hipMemcpyAsync(&root, w.bn, sizeof(root), hipMemcpyDeviceToHost, c->stream));
     if (w.eb) (void)hipEventRecord(w.eb, c->stream);
     if (triangles_out && n) TRY(hipMemcpyAsync(triangles_out, w.d_sorted, (size_t)n * 112, hipMemcpyDeviceToHost, c->stream));
@@ -1331,8 +1330,8 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
     sc.lights = (const float4*)c->d_lights;
     sc.n_nodes = n ? (int32_t)nn : 0;
     sc.n_tris = n_tri;
-    sc.n_lights = (int32_t)(lights.size() / 3);
-    sc.light_total = lightSum;
+    sc.n_lights = (int32_t)nLights;
+    sc.light_total = w.lightSum;
     for (int k = 0; k < 3; k++) { sc.root_min[k] = root.mn[k]; sc.root_max[k] = root.mx[k]; }
     sc.root_left = root.left >= 0 ? root.left : root.first;
     sc.root_count = root.left >= 0 ? 0 : root.count;

@@ -34,9 +34,46 @@ __global__ void __launch_bounds__(256) k_triangles(const Tri112* tris, uint32_t 
     }
     emissive[i] = e;
 }
-__global__ void __launch_bounds__(256) k_collect_lights(const Tri112* tris, uint32_t n, const uint32_t* emissive, const uint32_t* slot, Tri112* out) {
+// Light table rows of the emissive triangles, in triangle order: (V1, running area sum) (V2, material bits) (V3, 0).  The area is
+// computed as the host path computes it (same expression, same rounding) and goes to areas[]; k_light_sums fills in the sums.
+__global__ void __launch_bounds__(256) k_light_rows(const Tri112* tris, uint32_t n, const uint32_t* emissive, const uint32_t* slot, float4* lights, float* areas) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && emissive[i]) out[slot[i]] = tris[i];
+    if (i >= n || !emissive[i]) return;
+    const Tri112& t = tris[i];
+    const float* a = t.v[0]; const float* b = t.v[1]; const float* c = t.v[2];
+    const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    const float e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+    const uint32_t s = slot[i];
+    areas[s] = 0.5f * sqrtf((nx * nx + ny * ny) + nz * nz);
+    float4* row = lights + 3 * (size_t)s;
+    row[0] = make_float4(a[0], a[1], a[2], 0.0f);
+    row[1] = make_float4(b[0], b[1], b[2], __int_as_float(t.material));
+    row[2] = make_float4(c[0], c[1], c[2], 0.0f);
+}
+// The running area sum is a chain of float additions in triangle order (its rounding is part of the light table the host path
+// builds), so it cannot be split over threads: one wave walks it, 64 areas per round.  The sum travels along the lanes: every
+// step each lane adds its own area to the value of the lane below it (lane 0: to the sum so far), so after step k lanes 0..k
+// hold their final sums and repeating the step leaves them as they are — one shifted addition per link of the chain.
+__global__ void __launch_bounds__(64) k_light_sums(const float* __restrict__ areas, float4* __restrict__ lights, uint32_t n_lights, float* __restrict__ total) {
+    const uint32_t lane = threadIdx.x;
+    float carry = 0.0f;
+    float next = lane < n_lights ? areas[lane] : 0.0f;
+    for (uint32_t base = 0; base < n_lights; base += 64u) {
+        const float v = lane == 0u ? carry + next : next;   // lane 0 starts from the sum of the rounds before
+        next = base + 64u + lane < n_lights ? areas[base + 64u + lane] : 0.0f;
+        float r = v;
+#pragma unroll
+        for (int step = 0; step < 63; step++) {
+            // the value of lane - 1 (wave_shr:1); lane 0 has no such lane and reads +0, which leaves its (non-negative) sum as it is
+            const float below = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x138, 0xf, 0xf, true));
+            r = below + v;
+        }
+        if (base + lane < n_lights) lights[3 * (size_t)(base + lane)].w = r;
+        const uint32_t last = n_lights - base < 64u ? n_lights - base - 1u : 63u;
+        carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), (int)last));
+    }
+    if (lane == 0) *total = carry;
 }
 
 // which nodes own a quad record (interior, even depth) and which leaves need a big-leaf row
