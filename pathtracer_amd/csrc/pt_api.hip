@@ -68,6 +68,8 @@ struct pt_ctx {
     Group* group = nullptr;       // device_count > 1: this context only fans calls out to one member context per GPU
     std::string err;
     hipStream_t stream = nullptr;
+    hipStream_t stream_connect = nullptr;   // the connect stage of a bounce runs here, beside extend of the next bounce
+    hipEvent_t ev_shaded = nullptr, ev_connected = nullptr;
     int num_cu = 256;
     // scene
     DevScene sc{};
@@ -482,6 +484,9 @@ static int impl_create_single(const pt_config* cfg, pt_ctx** out) {
     c->cfg = *cfg;
     hipError_t e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_connect, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_shaded, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_connected, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipMemset(c->d_ctl, 0, sizeof(Ctl));
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
@@ -522,6 +527,9 @@ int pt_destroy(pt_ctx* c) {
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->stream_connect) { (void)hipStreamSynchronize(c->stream_connect); (void)hipStreamDestroy(c->stream_connect); }
+    if (c->ev_shaded) (void)hipEventDestroy(c->ev_shaded);
+    if (c->ev_connected) (void)hipEventDestroy(c->ev_connected);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PT_OK;
@@ -828,6 +836,10 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
         }
         if (generate_only) break;
         int cur = 0;
+        // connect(b) only meets shade(b) (its rays) and shade(b + 1) (the planes, the shadow queue, the cursors): it runs on a
+        // stream of its own beside extend(b + 1), whose tail it fills.  Per-stage timing keeps the stages apart on one stream.
+        const bool beside = c->cfg.stage_timing != 1;
+        bool connectPending = false;
         for (int b = 0; b < max_bounces; b++) {
             rp.bounce = b;
             rp.last_bounce = (b == max_bounces - 1) ? 1 : 0;
@@ -836,6 +848,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
                 launchExtend(c, stats, cur, (uint32_t)(b == 0 ? c->refill_primary : c->refill_bounce));
                 c->host_stats.extend_launches++;
             }
+            if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_connected, 0)); connectPending = false; }
             {
                 StageTimer t(c, 2);
                 hipLaunchKernelGGL(k_shade, dim3(c->grid_shade), dim3(PT_SHADE_BLOCK), 0, c->stream, c->sc, rp, c->q, c->d_ctl, cur);
@@ -843,15 +856,23 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             }
             if (rp.nee && c->sc.n_lights > 0) {
                 StageTimer t(c, 3);
-                if (stats) {
-                    hipLaunchKernelGGL(k_connect<true>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
-                } else {
-                    hipLaunchKernelGGL(k_connect<false>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, (uint32_t)c->refill_bounce);
+                hipStream_t on = c->stream;
+                if (beside) {
+                    HIPCHECK(c, hipEventRecord(c->ev_shaded, c->stream));
+                    HIPCHECK(c, hipStreamWaitEvent(c->stream_connect, c->ev_shaded, 0));
+                    on = c->stream_connect;
                 }
+                if (stats) {
+                    hipLaunchKernelGGL(k_connect<true>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, on, c->sc, c->q, c->d_ctl, cur, (uint32_t)c->refill_bounce);
+                } else {
+                    hipLaunchKernelGGL(k_connect<false>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, on, c->sc, c->q, c->d_ctl, cur, (uint32_t)c->refill_bounce);
+                }
+                if (beside) { HIPCHECK(c, hipEventRecord(c->ev_connected, c->stream_connect)); connectPending = true; }
                 c->host_stats.connect_launches++;
             }
             cur ^= 1;
         }
+        if (connectPending) HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_connected, 0));
         hipLaunchKernelGGL(k_resolve, dim3(launchGrid(c->slots)), dim3(PT_BLOCK), 0, c->stream, c->d_sum, (const float4*)c->q.plane, c->slots, ns);
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, (unsigned long long)c->local_pixels * ns);
     }

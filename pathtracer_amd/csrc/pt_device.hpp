@@ -80,7 +80,8 @@ struct DevScene {
 // Counters and queue sizes shared by the stages of one context (device memory).
 struct Ctl {
     uint32_t count[2];        // live rays in the ping/pong path queues
-    uint32_t shadow_count;    // rays in the shadow queue
+    uint32_t shadow_count[2]; // rays in the shadow queue, by the parity of the bounce that filled it (connect of one bounce may still be reading its
+                              // count while extend of the next bounce clears the other)
     uint32_t cursor_extend;   // next unclaimed ray of the running extend launch
     uint32_t cursor_connect;
     unsigned long long paths, extend_rays, shadow_rays, extend_steps, extend_tris, shadow_steps, shadow_tris, stack_overflows;

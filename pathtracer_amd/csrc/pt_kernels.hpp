@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // counters of the stages that follow this launch
         ctl->count[cur ^ 1] = 0;
-        ctl->shadow_count = 0;
+        ctl->shadow_count[cur] = 0;
         atomicAdd(&ctl->extend_rays, (unsigned long long)n);
     }
     uint32_t steps = 0, tris = 0, overflow = 0;
@@ -170,12 +170,12 @@ struct ConnectSource {
 };
 
 template <bool STATS>
-__global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScene sc, Queues q, Ctl* ctl, uint32_t refillMin) {
+__global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
     unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
-    const uint32_t n = ctl->shadow_count;
+    const uint32_t n = ctl->shadow_count[cur];
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->shadow_rays, (unsigned long long)n);
     uint32_t steps = 0, tris = 0, overflow = 0;
     ConnectSource src;
@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DevSce
             else if (addIt) q.plane[birth] = to4(from4(q.plane[birth]) + add);
         }
         uint32_t slotOut, sOut;
-        blockAppend2(survive, shadow, &ctl->count[nxt], &ctl->shadow_count, s_append[it & 1u], &slotOut, &sOut);
+        blockAppend2(survive, shadow, &ctl->count[nxt], &ctl->shadow_count[cur], s_append[it & 1u], &slotOut, &sOut);
         if (survive) {
             ntStore(&q.o[nxt][slotOut], make_float4(newO.x, newO.y, newO.z, __uint_as_float(birth)));
             ntStore(&q.d[nxt][slotOut], make_float4(newD.x, newD.y, newD.z, __uint_as_float(newFlags)));
@@ -554,7 +554,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src
 __global__ void k_set_ctl(Ctl* ctl, uint32_t count0, unsigned long long paths) {
     ctl->count[0] = count0;
     ctl->count[1] = 0;
-    ctl->shadow_count = 0;
+    ctl->shadow_count[0] = ctl->shadow_count[1] = 0;
     ctl->cursor_extend = 0;
     ctl->cursor_connect = 0;
     ctl->paths += paths;
