@@ -410,6 +410,9 @@ def main():
         # time.  The same figures from the frame whose stages ran back to back, the kernel having the GPU to itself:
         alone = traversal_roofline(counted, staged, cost["k_extend"], count_quads(run.nodes), int(run.tris.size), committed_pmc(args.workload))
         roof["kernel_alone"] = {k: alone[k] for k in ("bound", "achieved", "frac", "avg_launch_ms", "extend_mrays_per_s")}
+        roof["kernel_alone"]["fracs"] = {alone["bound"]: alone["frac"], **{k: v["frac"] for k, v in alone["other_roofs"].items()}}
+        roof["kernel_alone"]["bounce_extend_mrays_per_s"] = ((staged["extend_rays"] - staged["paths"]) /
+                                                             max(1e-9, (staged["ms_extend"] - staged["ms_extend_primary"]) * 1e-3) / 1e6)
         bounce_rays = st["extend_rays"] - st["paths"]
         bounce_ms = st["ms_extend"] - st["ms_extend_primary"]
         roof["bounce_extend_mrays_per_s"] = bounce_rays / max(1e-9, bounce_ms * 1e-3) / 1e6

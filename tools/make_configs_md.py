@@ -16,18 +16,21 @@ def main():
     print("c4 and c5 use synthetic stand-ins of the named triangle counts; their lines are the single-GPU leg of the 8-GPU configurations (every rank holds")
     print("the whole scene and traces its own tiles).  Roofs: vmem = vector-memory return rate (9,830 GB/s of distinct 16-byte loads), valu = vector-ALU issue")
     print("(39.3 T lane-op/s), hbm = 8,000 GB/s; the bound named is the roof the extend kernel sits closest to.\n")
+    print("The timed frames run connect of a bounce beside extend of the next one, so an extend launch shares the GPU for part of its time: the")
+    print("extend columns and the roof fractions are those of the frame whose stages ran back to back (the kernel alone); `live frac` is the")
+    print("bound's fraction from the extend launches of the timed frames themselves.\n")
     print("| config | workload | triangles | ms/step | Mrays/s (all rays) | extend Mrays/s | bounce-only extend Mrays/s | quad steps/ray | tri tests/ray | bound | frac "
-          "| vmem frac | valu frac | hbm frac | CPU port Mrays/s (all threads) | CPU port Mrays/s (1 thread) |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+          "| vmem frac | valu frac | hbm frac | live frac | CPU port Mrays/s (all threads) | CPU port Mrays/s (1 thread) |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for label, name in names:
         d = json.load(open(os.path.join(root, name + ".json")))
         r, c, cpu = d["roofline"], d["config"], d.get("cpu_baseline") or {}
-        fr = {r["bound"]: r["frac"]}
-        fr.update({k: v["frac"] for k, v in r["other_roofs"].items()})
+        a = r["kernel_alone"]
+        fr = a["fracs"]
         fmt = lambda v: "-" if v is None else "%.2f" % v
-        print(f"| {label} | {c['workload']} | {c['triangles']} | {d['ms_per_step']:.2f} | {d['value']:.0f} | {r['extend_mrays_per_s']:.0f} | {r['bounce_extend_mrays_per_s']:.0f} | "
-              f"{r['bvh_steps_per_ray']:.2f} | {r['tri_tests_per_ray']:.2f} | {r['bound']} | {r['frac']:.2f} | {fr['vmem']:.2f} | {fr['valu']:.2f} | {fr['hbm']:.3f} | "
-              f"{fmt(cpu.get('value'))} | {fmt(cpu.get('single_thread_value'))} |")
+        print(f"| {label} | {c['workload']} | {c['triangles']} | {d['ms_per_step']:.2f} | {d['value']:.0f} | {a['extend_mrays_per_s']:.0f} | {a['bounce_extend_mrays_per_s']:.0f} | "
+              f"{r['bvh_steps_per_ray']:.2f} | {r['tri_tests_per_ray']:.2f} | {a['bound']} | {a['frac']:.2f} | {fr['vmem']:.2f} | {fr['valu']:.2f} | {fr['hbm']:.3f} | "
+              f"{r['frac']:.2f} ({r['bound']}) | {fmt(cpu.get('value'))} | {fmt(cpu.get('single_thread_value'))} |")
     print("\nc1 is one sample of a 512x512 frame (0.26M paths): the frame is launch- and tail-bound, not traversal-bound.")
 
 
