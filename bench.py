@@ -252,7 +252,10 @@ def traversal_roofline(counted, timed, kernel_cost, n_quads, n_tris, pmc):
             "valu_instr_per_interior_iteration": i_int, "valu_instr_per_leaf_phase": i_leaf, "lane_ops_per_ray": laneops_per_ray,
             "lane_utilisation": {"interior": lane_int, "leaf": lane_leaf,
                                  "overall": (counted["extend_steps"] * i_int + counted["extend_tris"] * i_leaf) / max(1, 64 * issued)},
-            "issue_model_wave_instr_per_ray": issued / rays, "valu_busy_pmc": pmc.get("valu_busy")}
+            "issue_model_wave_instr_per_ray": issued / rays, "valu_busy_pmc": pmc.get("valu_busy"),
+            # cross-check of the instruction counts: wave iterations x VALU instructions per iteration against the hardware's count of
+            # the same kernel (committed PMC pass; the two loops only, so a little below 1 is expected)
+            "issue_model_over_sq_insts_valu": (issued / max(1, counted["extend_launches"]) / pmc["sq_insts_valu_per_launch"]) if pmc.get("sq_insts_valu_per_launch") else None}
     hbm = {"bound": "hbm", "bound_note": "ray records in and out plus one pass over the tree and the hot triangle records per launch; the walk's re-use is served by L2 / Infinity Cache",
            "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "bytes_per_launch": hbm_alg, "scene_bytes": scene_bytes}
     # the roof that binds is the one the kernel sits closest to; the other two stay in the line

@@ -361,7 +361,8 @@ static inline uint32_t packLeaf(int32_t first, int32_t count, uint32_t bigIndex)
 // reference, sign bit set = leaf whose remaining triangles are [leafJ, leafEnd).
 #define PT_KEY_MISS 0xFFFFFFFFu
 // Markers for tools/isa_cost.py: with -DPT_ISA_MARKS the assembly carries comments around one interior iteration and one
-// leaf phase, between which the tool counts vector-ALU instructions.  The shipped build has none.
+// leaf phase, between which the tool counts vector-ALU instructions, and around the rarely taken part of the interior step
+// (the stack spilling out of LDS), which the tool leaves out of the count.  The shipped build has none.
 #ifdef PT_ISA_MARKS
 #define PT_MARK(name) asm volatile("; PT_MARK " name)
 #else
@@ -576,10 +577,12 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                             if (np >= 2) at[(np - 2) * PT_WAVE] = make_uint2(e2, k2 & ~3u);
                             at[(np - 1) * PT_WAVE] = make_uint2(e1, k1 & ~3u);
                             sp += np;
-                        } else {
+                        } else {   // the stack leaves LDS: a few steps in a thousand
+                            PT_MARK("cold_begin");
                             if (np == 3) push(e3, __uint_as_float(k3 & ~3u));
                             if (np >= 2) push(e2, __uint_as_float(k2 & ~3u));
                             push(e1, __uint_as_float(k1 & ~3u));
+                            PT_MARK("cold_end");
                         }
                     }
                     if (k0 != PT_KEY_MISS) enter(e0);

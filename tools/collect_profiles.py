@@ -39,6 +39,7 @@ def traffic_entry(vals, source, command):
                   "request-size breakdown is the figure used). L2 memory-side requests: Infinity-Cache hits are included, so this is an upper bound on HBM bytes.",
         "tcc_hit_rate": vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]),
         "valu_busy": vals["SQ_INSTS_VALU"] * 4 / simd_cycles,
+        "sq_insts_valu_per_launch": vals["SQ_INSTS_VALU"],
         "valu_busy_method": "SQ_INSTS_VALU (wave instructions, 4 cycles each on a 16-lane SIMD) over 1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs, k_extend<false>, mean per dispatch",
         "waves_per_simd": 4 * vals["SQ_WAVE_CYCLES"] / simd_cycles,
         "waves_per_simd_method": "4 x SQ_WAVE_CYCLES over SIMD clocks: resident waves per SIMD averaged over the launch.  SQ_WAVE_CYCLES is taken to count in units "

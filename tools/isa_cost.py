@@ -7,7 +7,9 @@ instead of trusting a hand count.  pt_api.hip is compiled to assembly with -DPT_
 iteration and one leaf phase with comment markers; the body of a bracket is every basic block that lies on a path from
 its begin marker to its end marker (forward reachability from `begin` that stops at `end`, intersected with backward
 reachability from `end` that stops at `begin`), so loop rotation and block placement by the compiler do not matter.
-Inner loops of a body (the stack pop, the dealing of triangles to lanes) are counted once.
+Inner loops of a body (the stack pop, the dealing of triangles to lanes) are counted once; the part of the interior step that runs
+only when a ray's stack leaves LDS (bracketed by cold markers) is left out.  Cross-check against the hardware: the wave iterations
+the instrumented kernel counts times these costs should come close to SQ_INSTS_VALU of the same launch (tools/pmc_bench.sh).
 
   python tools/isa_cost.py            # prints the table and writes pathtracer_amd/isa_cost.json
   python tools/isa_cost.py --check    # exit 1 if the committed file differs from what the sources give now
@@ -116,11 +118,20 @@ def body_cost(blocks, succ, name):
         for s in ss:
             pred[s].append(i)
     body = reach(begin, end, succ) & reach(end, begin, pred)
+    # a rarely executed part of the body (bracketed by cold_begin / cold_end markers) does not belong to the cost of an iteration
+    cold_b = [i for i in body if blocks[i] and blocks[i][0] == "; PT_MARK cold_begin"]
+    cold_e = [i for i in body if blocks[i] and blocks[i][0] == "; PT_MARK cold_end"]
+    cold = set()
+    for b in cold_b:
+        for e in cold_e:
+            cold |= reach(b, e, succ) & reach(e, b, pred)
+    body -= cold
     cost = {"valu": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0}
     for i in sorted(body):
         for ins in blocks[i]:
             cost[classify(ins.split()[0])] += 1
     cost["blocks"] = len(body)
+    cost["cold_blocks_left_out"] = len(cold)
     return cost
 
 
