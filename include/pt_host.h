@@ -87,10 +87,11 @@ int pth_camera_state(const float* position3, const float* forward3, const float*
 
 /* An image file from the rgba32f read-out of pt_read_image (row 0 = bottom row, as the reference's display reads it,
  * PathTracer/Shaders/Quad/fragment.glsl:9-10; the reference itself never writes a file).
- * format:   PTH_IMAGE_PFM  RGB float32, lossless;  PTH_IMAGE_PPM  binary P6;  PTH_IMAGE_PNG  8-bit RGB.
+ * format:   PTH_IMAGE_PFM  RGB float32, lossless;  PTH_IMAGE_PPM  binary P6;  PTH_IMAGE_PNG  8-bit RGB;
+ *           PTH_IMAGE_EXR  OpenEXR 2 scan lines, float32 R/G/B, uncompressed, lossless (top row first, as the format has it).
  * transfer (8-bit formats): PTH_TRANSFER_DISPLAY  what the reference's window shows: clamp to [0,1], round(255 v);
  *                           PTH_TRANSFER_SRGB     v * exposure, clamp, sRGB encoding. */
-enum { PTH_IMAGE_PFM = 0, PTH_IMAGE_PPM = 1, PTH_IMAGE_PNG = 2 };
+enum { PTH_IMAGE_PFM = 0, PTH_IMAGE_PPM = 1, PTH_IMAGE_PNG = 2, PTH_IMAGE_EXR = 3 };
 enum { PTH_TRANSFER_DISPLAY = 0, PTH_TRANSFER_SRGB = 1 };
 int pth_image_write(const char* path, const float* rgba, int32_t width, int32_t height, int32_t format, int32_t transfer, float exposure);
 

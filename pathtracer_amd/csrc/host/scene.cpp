@@ -564,9 +564,51 @@ std::vector<unsigned char> encodePng(const std::vector<unsigned char>& rgb, int 
     return file;
 }
 
+// OpenEXR 2, one part, scan lines, no compression, three float32 channels (B, G, R: channels are stored in alphabetical
+// order), increasing y with row 0 of the file the TOP row (the read-out's row 0 is the bottom one).  Lossless like the PFM.
+std::vector<unsigned char> encodeExr(const float* rgba, int w, int h) {
+    std::vector<unsigned char> f;
+    auto bytesOf = [&f](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; f.insert(f.end(), b, b + n); };
+    auto i32 = [&](int32_t v) { bytesOf(&v, 4); };
+    auto f32 = [&](float v) { bytesOf(&v, 4); };
+    auto text = [&](const char* t) { bytesOf(t, std::strlen(t) + 1); };
+    auto attribute = [&](const char* name, const char* type, int32_t size) { text(name); text(type); i32(size); };
+    i32(20000630);                                     // magic
+    i32(2);                                            // version 2, no flags: single part, scan lines, short names
+    attribute("channels", "chlist", 3 * 18 + 1);
+    for (const char* c : {"B", "G", "R"}) { text(c); i32(2 /* FLOAT */); f.push_back(0); f.push_back(0); f.push_back(0); f.push_back(0); i32(1); i32(1); }
+    f.push_back(0);
+    attribute("compression", "compression", 1);
+    f.push_back(0);                                    // NO_COMPRESSION
+    attribute("dataWindow", "box2i", 16);
+    i32(0); i32(0); i32(w - 1); i32(h - 1);
+    attribute("displayWindow", "box2i", 16);
+    i32(0); i32(0); i32(w - 1); i32(h - 1);
+    attribute("lineOrder", "lineOrder", 1);
+    f.push_back(0);                                    // INCREASING_Y
+    attribute("pixelAspectRatio", "float", 4);
+    f32(1.0f);
+    attribute("screenWindowCenter", "v2f", 8);
+    f32(0.0f); f32(0.0f);
+    attribute("screenWindowWidth", "float", 4);
+    f32(1.0f);
+    f.push_back(0);                                    // end of header
+    const size_t line = 8 + (size_t)w * 12;            // y, byte count, then the three channels of the row
+    uint64_t at = f.size() + (size_t)h * 8;
+    for (int y = 0; y < h; y++) { bytesOf(&at, 8); at += line; }
+    for (int y = 0; y < h; y++) {
+        i32(y);
+        i32((int32_t)((size_t)w * 12));
+        const float* row = rgba + (size_t)(h - 1 - y) * w * 4;
+        for (int c = 2; c >= 0; c--)
+            for (int x = 0; x < w; x++) f32(row[4 * x + c]);
+    }
+    return f;
+}
+
 void writeImage(const char* path, const float* rgba, int w, int h, int format, int transfer, float exposure) {
     if (!path || !rgba || w < 1 || h < 1) throw std::runtime_error("pth_image_write: bad argument");
-    if (format < 0 || format > 2 || transfer < 0 || transfer > 1) throw std::runtime_error("pth_image_write: unknown format or transfer");
+    if (format < 0 || format > 3 || transfer < 0 || transfer > 1) throw std::runtime_error("pth_image_write: unknown format or transfer");
     std::vector<unsigned char> bytes;
     if (format == 0) {                                                      // PFM: RGB float, little endian, bottom row first
         char head[64];
@@ -575,6 +617,8 @@ void writeImage(const char* path, const float* rgba, int w, int h, int format, i
         bytes.resize(n + (size_t)w * h * 12);
         unsigned char* o = bytes.data() + n;
         for (size_t i = 0; i < (size_t)w * h; i++) std::memcpy(o + 12 * i, rgba + 4 * i, 12);
+    } else if (format == 3) {
+        bytes = encodeExr(rgba, w, h);
     } else {
         const std::vector<unsigned char> rgb = quantize(rgba, w, h, transfer, exposure);
         if (format == 1) {                                                  // PPM P6

@@ -60,12 +60,12 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-IMAGE_FORMATS = {"pfm": 0, "ppm": 1, "png": 2}
+IMAGE_FORMATS = {"pfm": 0, "ppm": 1, "png": 2, "exr": 3}
 TRANSFERS = {"display": 0, "srgb": 1}
 
 
 def write_image(path, rgba, transfer="display", exposure=1.0, format=None):
-    """Write the (H, W, 4) float32 read-out of Wavefront.read_image (row 0 = bottom) as .pfm (lossless), .ppm or .png.
+    """Write the (H, W, 4) float32 read-out of Wavefront.read_image (row 0 = bottom) as .pfm or .exr (float32, lossless), .ppm or .png.
     transfer="display" is what the reference's window shows (Shaders/Quad/fragment.glsl:9-10: clamp, 8 bits, no gamma);
     "srgb" applies exposure and the sRGB curve."""
     rgba = np.ascontiguousarray(rgba, dtype=np.float32)

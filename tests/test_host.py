@@ -152,7 +152,7 @@ def test_references_are_the_insertion_order(host):
 
 
 def test_image_writers(host, tmp_path):
-    """PFM is lossless; PPM and PNG hold what the reference's window would show (clamp, 8 bits, row 0 at the bottom,
+    """PFM and EXR are lossless; PPM and PNG hold what the reference's window would show (clamp, 8 bits, row 0 at the bottom,
     Shaders/Quad/fragment.glsl:9-10) or the sRGB-encoded exposure; the PNG is a valid file (CRC, zlib, Adler)."""
     import struct
     import zlib
@@ -196,6 +196,31 @@ def test_image_writers(host, tmp_path):
     head = b"PF\n%d %d\n-1.0\n" % (w, h)
     assert b.startswith(head)
     assert np.array_equal(np.frombuffer(b[len(head):], np.float32).view(np.uint32).reshape(h, w, 3), img[:, :, :3].view(np.uint32))
+
+    # OpenEXR: magic, version, the attributes a reader requires, the line offset table, one uncompressed chunk per scan line
+    exr = tmp_path / "a.exr"
+    host.write_image(exr, img)
+    b = open(exr, "rb").read()
+    assert struct.unpack("<II", b[:8]) == (20000630, 2)
+    at, attrs = 8, {}
+    while b[at] != 0:
+        name_end = b.index(b"\0", at)
+        type_end = b.index(b"\0", name_end + 1)
+        size, = struct.unpack("<i", b[type_end + 1:type_end + 5])
+        attrs[b[at:name_end].decode()] = (b[name_end + 1:type_end].decode(), b[type_end + 5:type_end + 5 + size])
+        at = type_end + 5 + size
+    at += 1
+    assert {"channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio", "screenWindowCenter", "screenWindowWidth"} <= set(attrs)
+    assert attrs["channels"][0] == "chlist" and attrs["channels"][1] == b"".join(c + b"\0" + struct.pack("<iB3xii", 2, 0, 1, 1) for c in (b"B", b"G", b"R")) + b"\0"
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, w - 1, h - 1) == struct.unpack("<4i", attrs["displayWindow"][1])
+    offsets = struct.unpack("<%dQ" % h, b[at:at + 8 * h])
+    assert offsets[0] == at + 8 * h and len(b) == offsets[-1] + 8 + 12 * w
+    for y in (0, 1, h - 1):
+        yy, nbytes = struct.unpack("<ii", b[offsets[y]:offsets[y] + 8])
+        assert (yy, nbytes) == (y, 12 * w)
+        chans = np.frombuffer(b[offsets[y] + 8:offsets[y] + 8 + 12 * w], np.uint32).reshape(3, w)   # B, G, R planes of the row
+        assert np.array_equal(chans[::-1].T, img[h - 1 - y, :, :3].view(np.uint32))
 
     for transfer, exposure in (("display", 1.0), ("srgb", 0.75)):
         png, ppm = tmp_path / "a.png", tmp_path / "a.ppm"
