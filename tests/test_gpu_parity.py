@@ -216,6 +216,41 @@ def test_gpu_bvh_build_is_byte_identical(pa, bundled, soup50k):
     wf.close()
 
 
+def test_device_built_light_table_and_small_subtrees(pa, ob):
+    """pt_build_scene on little scenes that sit on the seams of the device code: triangle counts around the small-subtree
+    limit (one wave finishes a node of <= 64 primitives) and emissive-triangle counts around the 64-lane rounds of the running
+    area sum.  Arrays == the host build's; a next-event-estimation frame == the same scene uploaded from the host (whose light
+    table is summed on the CPU, one float addition after the other)."""
+    from pathtracer_amd.types import TRIANGLE, material, DIFFUSE
+    rng = np.random.default_rng(21)
+    mats = np.concatenate([material(color=(0.7, 0.7, 0.7, 0)), material(color=(1, 1, 1, 0), emissive=(4, 3, 2, 0))])
+    for n, n_lights in ((3, 1), (63, 63), (64, 64), (65, 65), (129, 128), (700, 193), (5000, 1500)):
+        tris = np.zeros(n, TRIANGLE)
+        c = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+        for v in ("v1", "v2", "v3"):
+            tris[v]["position"] = c + rng.uniform(-0.4, 0.4, (n, 3)).astype(np.float32)
+            tris[v]["normal"] = (0, 1, 0)
+        tris["material"] = 0
+        tris["material"][rng.permutation(n)[:n_lights]] = 1
+        want_t, want_n = _host_build(pa, tris)
+        dev = pa.Wavefront(nee=True, rng_mode=1)
+        got_t, got_n, _ = dev.build_scene(mats, tris, want_arrays=True)
+        assert got_n.tobytes() == want_n.tobytes() and got_t.tobytes() == want_t.tobytes(), n
+        ref = pa.Wavefront(nee=True, rng_mode=1)
+        ref.upload_scene(mats, want_t, want_n)
+        o = ob.Scene("")
+        fs, _ = o.camera((0, 0, 14), (0, 0, 0), 64, 48, use_scene=False, frames=1, samples=1)
+        imgs = []
+        for x in (dev, ref):
+            x.allocate(64, 48)
+            x.reset_stats()
+            x.invoke(fs, spp=4, max_bounces=3)
+            imgs.append(x.read_image())
+            assert n < 700 or x.stats()["shadow_rays"] > 100
+            x.close()
+        assert np.array_equal(bits(imgs[0]), bits(imgs[1])), (n, n_lights)
+
+
 def test_device_built_scene_renders_identically(pa, ob, bundled, wf_bundled):
     """pt_build_scene (build + repack on the GPU) against pt_upload_scene of the CPU-built arrays: same hits, same
     counters, same image, and the arrays handed back are the CPU build's."""
