@@ -108,9 +108,10 @@ const char* pt_last_error(pt_ctx* ctx);
 
 /* Replaces: Scene.CopyToDevice -> Buffer<T>.CopyToDevice for bindings 10/11/12,
  * PathTracer/Scene.cs:176-183, PathTracer/Library/Graphics/Buffer.cs:94-126.
- * Copies; validates child indices and leaf ranges (PT_E_BAD_BVH); repacks into 128-byte quad records (every
- * other level of the tree), 64-byte sibling-pair records and 48-byte hot/cold triangle records;
- * builds the emissive-triangle table. */
+ * Copies the three arrays to the GPU as they are; there the tree is checked (child indices, leaf ranges, every node
+ * referenced once, the leaves' triangle count, the depth against the traversal stack, material indices: PT_E_BAD_BVH /
+ * PT_E_INVALID_ARG, the scene installed before stays) and repacked into 128-byte quad records (every other level of
+ * the tree), 64-byte sibling-pair records, 48-byte hot/cold triangle records and the emissive-triangle table. */
 int pt_upload_scene(pt_ctx* ctx, const void* materials, int32_t n_materials,
                     const void* triangles, int32_t n_triangles,
                     const void* nodes, int32_t n_nodes);

@@ -196,53 +196,7 @@ void collectSpans(pt_ctx* c) {
     c->spans.clear();
 }
 
-// Validates the host's Node[] (Accelerator.cs:113-177 output shape) so that no kernel can
-// index out of bounds, and returns the tree depth.
-int validateBvh(pt_ctx* c, const HostNode* nodes, int n_nodes, int n_tris, int* depth_out) {
-    if (n_nodes == 0) { *depth_out = 0; return PT_OK; }
-    if ((n_nodes & 1) == 0) FAIL(c, PT_E_BAD_BVH, "node count %d is even: nodes are a root plus sibling pairs", n_nodes);
-    std::vector<int> depth(n_nodes, 0);
-    std::vector<uint8_t> seen(n_nodes, 0);
-    depth[0] = 1;
-    seen[0] = 1;
-    int maxDepth = 1;
-    long long leafTris = 0;
-    for (int i = 0; i < n_nodes; i++) {
-        const HostNode& nd = nodes[i];
-        if (!seen[i]) FAIL(c, PT_E_BAD_BVH, "node %d is not referenced by an earlier node", i);
-        if (nd.count > 0) {
-            if (nd.leftFirst < 0 || (long long)nd.leftFirst + nd.count > n_tris) FAIL(c, PT_E_BAD_BVH, "leaf %d references triangles [%d,%d) of %d", i, nd.leftFirst, nd.leftFirst + nd.count, n_tris);
-            leafTris += nd.count;
-        } else {
-            const int l = nd.leftFirst;
-            if (l <= i || (l & 1) == 0 || l + 1 >= n_nodes) FAIL(c, PT_E_BAD_BVH, "interior node %d has children at %d (need odd, > parent, < %d)", i, l, n_nodes - 1);
-            if (seen[l] || seen[l + 1]) FAIL(c, PT_E_BAD_BVH, "node pair %d is referenced twice", l);
-            seen[l] = seen[l + 1] = 1;
-            depth[l] = depth[l + 1] = depth[i] + 1;
-            maxDepth = std::max(maxDepth, depth[i] + 1);
-        }
-    }
-    if (leafTris != n_tris) FAIL(c, PT_E_BAD_BVH, "leaves cover %lld triangles, %d uploaded", leafTris, n_tris);
-    *depth_out = maxDepth;
-    return PT_OK;
-}
-
 int launchGrid(uint32_t n) { return (int)((n + PT_BLOCK - 1) / PT_BLOCK); }
-
-// One row of the light table: (V1, running area sum) (V2, material bits) (V3, 0); areas are summed in triangle order.
-void appendLight(const HostTriangle& t, std::vector<float4>& lights, float& lightSum) {
-    const float* a = t.v[0].pos; const float* b = t.v[1].pos; const float* cc = t.v[2].pos;
-    float mbits;
-    memcpy(&mbits, &t.material, 4);
-    const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-    const float e2[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]};
-    const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
-    const float area = 0.5f * sqrtf((nx * nx + ny * ny) + nz * nz);
-    lightSum = lightSum + area;
-    lights.push_back(make_float4(a[0], a[1], a[2], lightSum));
-    lights.push_back(make_float4(b[0], b[1], b[2], mbits));
-    lights.push_back(make_float4(cc[0], cc[1], cc[2], 0.0f));
-}
 
 }  // namespace
 
@@ -560,156 +514,6 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
         default: FAIL(c, PT_E_INVALID_ARG, "unknown option %d", key);
     }
     return PT_OK;
-}
-
-// The uploaded scene in the device layouts, still on the host: packed once, installed on one GPU or on several.
-struct QuadRecord { float box[6][4]; uint32_t entry[4]; uint32_t pad[4]; };
-static_assert(sizeof(QuadRecord) == 128, "quad record is one 128-byte line");
-struct PackedScene {
-    std::vector<HostNode> pairs;
-    std::vector<QuadRecord> quads;
-    std::vector<uint2> big;
-    std::vector<float4> hot, cold, lights;
-    const void* mats = nullptr;
-    int32_t n_mat = 0, n_tri = 0, n_nodes = 0;
-    float lightSum = 0.0f;
-    HostNode root{};
-};
-
-// Validates the host's arrays (nothing a kernel indexes with may be out of range) and repacks them; `c` only receives errors.
-static int packScene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles, int32_t n_tri, const void* nodes, int32_t n_nodes, PackedScene& out) {
-    if (n_mat < 0 || n_tri < 0 || n_nodes < 0 || (n_mat && !materials) || (n_tri && !triangles) || (n_nodes && !nodes)) FAIL(c, PT_E_INVALID_ARG, "pt_upload_scene: bad counts or null arrays");
-    const HostNode* hn = (const HostNode*)nodes;
-    const HostTriangle* ht = (const HostTriangle*)triangles;
-    const HostMaterial* hm = (const HostMaterial*)materials;
-    if (n_tri == 0) n_nodes = 0;   // Accelerator.Build on an empty scene leaves a childless root (Accelerator.cs:120-125)
-    int depth = 0;
-    int rc = validateBvh(c, hn, n_nodes, n_tri, &depth);
-    if (rc != PT_OK) return rc;
-    // the wide traversal pushes up to three entries on each of its (depth + 1) / 2 levels
-    if (depth > PT_STACK_TOTAL || 3 * ((depth + 1) / 2) > PT_STACK_TOTAL) FAIL(c, PT_E_BAD_BVH, "BVH depth %d exceeds the traversal stack (%d entries)", depth, PT_STACK_TOTAL);
-    for (int i = 0; i < n_tri; i++)
-        if (ht[i].material < 0 || ht[i].material >= n_mat) FAIL(c, PT_E_INVALID_ARG, "triangle %d has material %d of %d", i, ht[i].material, n_mat);
-
-    const int n_pairs = n_nodes > 0 ? (n_nodes - 1) / 2 : 0;
-    out.mats = materials;
-    out.n_mat = n_mat; out.n_tri = n_tri; out.n_nodes = n_nodes;
-    if (n_nodes > 0) out.root = hn[0];
-    std::vector<float4>&hot = out.hot, &cold = out.cold, &lights = out.lights;
-    hot.resize((size_t)n_tri * 3);
-    cold.resize((size_t)n_tri * 3);
-    float lightSum = 0.0f;
-    for (int i = 0; i < n_tri; i++) {
-        const HostTriangle& t = ht[i];
-        const float* a = t.v[0].pos; const float* b = t.v[1].pos; const float* cc = t.v[2].pos;
-        float mbits;
-        memcpy(&mbits, &t.material, 4);
-        const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};     // Triangle.cs:17
-        const float e2[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]};  // Triangle.cs:18
-        hot[3 * (size_t)i] = make_float4(a[0], a[1], a[2], mbits);
-        hot[3 * (size_t)i + 1] = make_float4(e1[0], e1[1], e1[2], 0.0f);
-        hot[3 * (size_t)i + 2] = make_float4(e2[0], e2[1], e2[2], 0.0f);
-        for (int k = 0; k < 3; k++) cold[3 * (size_t)i + k] = make_float4(t.v[k].nrm[0], t.v[k].nrm[1], t.v[k].nrm[2], 0.0f);
-        const HostMaterial& m = hm[t.material];
-        if (m.emissive[0] > 0 || m.emissive[1] > 0 || m.emissive[2] > 0) appendLight(t, lights, lightSum);   // shade.glsl:366
-    }
-    out.lightSum = lightSum;
-    // sibling pair k = nodes[2k+1], nodes[2k+2]: the node array shifted by one node lands on 64-byte lines;
-    // each node's leftFirst word becomes its traversal entry
-    std::vector<HostNode>& pairs = out.pairs;
-    pairs.assign(hn + (n_pairs ? 1 : 0), hn + (n_pairs ? 1 + 2 * (size_t)n_pairs : 0));
-    std::vector<uint2>& big = out.big;
-    std::vector<uint32_t> leafEntry(pairs.size() + 1, 0u);   // by node index
-    for (size_t i = 0; i < pairs.size(); i++) {
-        HostNode& nd = pairs[i];
-        if (nd.count <= 0) continue;   // interior: the entry is the left child's index itself
-        const uint32_t e = packLeaf(nd.leftFirst, nd.count, (uint32_t)big.size());
-        if (!leafFitsPacked(nd.leftFirst, nd.count)) big.push_back(make_uint2((uint32_t)nd.leftFirst, (uint32_t)nd.count));
-        memcpy(&nd.leftFirst, &e, 4);
-        leafEntry[i + 1] = e;
-    }
-    if (big.size() >= PT_LEAF_MAX_FIRST) FAIL(c, PT_E_BAD_BVH, "%zu leaves of more than %d triangles", big.size(), PT_LEAF_MAX_COUNT);
-    // quad records: every other level of the tree, starting at the root
-    std::vector<QuadRecord>& quads = out.quads;
-    if (n_pairs > 0 && hn[0].count <= 0) {
-        std::vector<std::pair<int32_t, uint32_t>> work;   // (interior node, its quad)
-        quads.emplace_back();
-        work.emplace_back(0, 0u);
-        while (!work.empty()) {
-            const int32_t node = work.back().first;
-            const uint32_t qi = work.back().second;
-            work.pop_back();
-            int32_t kids[4];
-            int nk = 0;
-            for (int32_t ch = hn[node].leftFirst; ch <= hn[node].leftFirst + 1; ch++) {
-                if (hn[ch].count > 0) kids[nk++] = ch;
-                else { kids[nk++] = hn[ch].leftFirst; kids[nk++] = hn[ch].leftFirst + 1; }
-            }
-            QuadRecord q{};
-            for (int k = 0; k < nk; k++) {
-                const HostNode& kd = hn[kids[k]];
-                for (int a = 0; a < 3; a++) { q.box[a][k] = kd.mn[a]; q.box[3 + a][k] = kd.mx[a]; }
-                if (kd.count > 0) q.entry[k] = leafEntry[kids[k]];
-                else {
-                    q.entry[k] = (uint32_t)quads.size() + 1u;
-                    work.emplace_back(kids[k], (uint32_t)quads.size());
-                    quads.emplace_back();
-                }
-            }
-            quads[qi] = q;
-        }
-        if (quads.size() >= 0x7FFFFFFFu) FAIL(c, PT_E_BAD_BVH, "%zu quad records", quads.size());
-    }
-    return PT_OK;
-}
-
-// Copies a packed scene to the context's GPU; the context's previous scene is released only once the new one is complete.
-static int installScene(pt_ctx* c, const PackedScene& p) {
-    HIPCHECK(c, hipSetDevice(c->cfg.device));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
-    void* fresh[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const void* src[7] = {p.pairs.data(), p.quads.data(), p.big.data(), p.hot.data(), p.cold.data(), p.mats, p.lights.data()};
-    const size_t bytes[7] = {p.pairs.size() * sizeof(HostNode), p.quads.size() * sizeof(QuadRecord), p.big.size() * sizeof(uint2), p.hot.size() * sizeof(float4),
-                             p.cold.size() * sizeof(float4), (size_t)p.n_mat * 48, p.lights.size() * sizeof(float4)};
-    for (int k = 0; k < 7; k++) {
-        if (bytes[k] == 0) continue;
-        hipError_t e = hipMalloc(&fresh[k], bytes[k]);
-        if (e == hipSuccess) e = hipMemcpy(fresh[k], src[k], bytes[k], hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            for (void* m : fresh) if (m) (void)hipFree(m);
-            FAIL(c, (e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "scene upload (%zu bytes): %s", bytes[k], hipGetErrorString(e));
-        }
-    }
-    freeScene(c);
-    c->d_pairs = fresh[0]; c->d_quads = fresh[1]; c->d_big = fresh[2]; c->d_hot = fresh[3]; c->d_cold = fresh[4]; c->d_mats = fresh[5]; c->d_lights = fresh[6];
-    DevScene& sc = c->sc;
-    sc.pairs = (const float4*)c->d_pairs;
-    sc.quads = (const float4*)c->d_quads;
-    sc.big = (const uint2*)c->d_big;
-    sc.tri_hot = (const float4*)c->d_hot;
-    sc.tri_cold = (const float4*)c->d_cold;
-    sc.mats = (const float4*)c->d_mats;
-    sc.lights = (const float4*)c->d_lights;
-    sc.n_nodes = p.n_nodes;
-    sc.n_tris = p.n_tri;
-    sc.n_lights = (int32_t)(p.lights.size() / 3);
-    sc.light_total = p.lightSum;
-    if (p.n_nodes > 0) {
-        for (int k = 0; k < 3; k++) { sc.root_min[k] = p.root.mn[k]; sc.root_max[k] = p.root.mx[k]; }
-        sc.root_left = p.root.leftFirst;
-        sc.root_count = p.root.count;
-    }
-    c->has_scene = true;
-    return PT_OK;
-}
-
-static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles, int32_t n_tri, const void* nodes, int32_t n_nodes) {
-    if (!c) return PT_E_INVALID_ARG;
-    PackedScene packed;
-    int rc = packScene(c, materials, n_mat, triangles, n_tri, nodes, n_nodes, packed);
-    if (rc != PT_OK) return rc;
-    if (c->group) return c->group->all(c, [&](pt_ctx* m) { return installScene(m, packed); });
-    return installScene(c, packed);
 }
 
 static int impl_resize(pt_ctx* c, int32_t width, int32_t height) {
@@ -1214,6 +1018,120 @@ static int impl_build_bvh(pt_ctx* c, const void* triangles_in, int32_t n_tri, vo
     return PT_OK;
 }
 
+// Buffers of one scene installation (pt_upload_scene, pt_build_scene).  Everything is made in buffers of the call; the context's
+// scene is replaced only when all of it exists, and the destructor releases whatever is still held on any way out (error returns
+// and exceptions alike) after waiting for the stream, so nothing queued can outlive the buffers or this object.
+struct SceneWork {
+    pt_ctx* c;
+    ptbuild::Tri112 *d_in = nullptr, *d_sorted = nullptr;
+    ptbuild::Node32* d_nodes = nullptr;
+    ptbuild::BNode* bn = nullptr;
+    uint32_t *d_flagA = nullptr, *d_idxA = nullptr, *d_flagB = nullptr, *d_idxB = nullptr, *d_bad = nullptr;
+    uint32_t *d_parent = nullptr, *d_refs = nullptr, *d_anc[2] = {nullptr, nullptr}, *d_dep[2] = {nullptr, nullptr};
+    ptrepack::UploadCheck* d_check = nullptr;
+    void* tmp = nullptr;
+    size_t tmpBytes = 0;
+    void *pairs = nullptr, *quads = nullptr, *big = nullptr, *hot = nullptr, *cold = nullptr, *mats = nullptr, *lights = nullptr;   // the new scene
+    hipEvent_t ea = nullptr, eb = nullptr;
+    float lightSum = 0.0f;     // written by copies queued on the stream
+    ptbuild::BNode root{};
+    uint32_t nLights = 0;
+    explicit SceneWork(pt_ctx* ctx) : c(ctx) {}
+    SceneWork(const SceneWork&) = delete;
+    SceneWork& operator=(const SceneWork&) = delete;
+    ~SceneWork() {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        void* all[] = {d_in, d_sorted, d_nodes, bn, d_flagA, d_idxA, d_flagB, d_idxB, d_bad, d_parent, d_refs, d_anc[0], d_anc[1], d_dep[0], d_dep[1], d_check, tmp,
+                       pairs, quads, big, hot, cold, mats, lights};
+        for (void* p : all) if (p) (void)hipFree(p);
+        if (ea) c->pool.push_back(ea);
+        if (eb) c->pool.push_back(eb);
+    }
+};
+#define TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { FAIL(c, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s", #call, hipGetErrorString(_e)); } } while (0)
+
+// The device scene — hot / cold triangles, light table, pair and quad records, big-leaf rows — from triangles in tree order
+// (w.d_sorted) and the tree as BNode records whose children sit side by side (w.bn, nn of them): queued on the context's stream,
+// except for two small read-backs that size the allocations.
+static int repackOnDevice(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn, const void* materials, int32_t n_mat) {
+    const size_t flagsLen = std::max<size_t>(std::max<size_t>(n, nn), 1);
+    TRY(hipMalloc((void**)&w.d_flagA, flagsLen * 4));
+    TRY(hipMalloc((void**)&w.d_idxA, flagsLen * 4));
+    TRY(hipMalloc((void**)&w.d_flagB, flagsLen * 4));
+    TRY(hipMalloc((void**)&w.d_idxB, flagsLen * 4));
+    TRY(hipMalloc((void**)&w.d_bad, 4));
+    TRY(hipMemsetAsync(w.d_bad, 0, 4, c->stream));
+    if (n_mat) {
+        TRY(hipMalloc(&w.mats, (size_t)n_mat * 48));
+        TRY(hipMemcpyAsync(w.mats, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, c->stream));
+    }
+    // ---- triangles: hot / cold records, the light table
+    if (n) {
+        TRY(hipMalloc(&w.hot, (size_t)n * 48));
+        TRY(hipMalloc(&w.cold, (size_t)n * 48));
+        hipLaunchKernelGGL(ptrepack::k_triangles, dim3(launchGrid(n)), dim3(256), 0, c->stream, w.d_sorted, n, (const float4*)w.mats, n_mat,
+                           (float4*)w.hot, (float4*)w.cold, w.d_flagA, w.d_bad);
+        TRY(ptrepack::exclusiveScan(c->stream, w.d_flagA, w.d_idxA, n, &w.tmp, &w.tmpBytes));
+        uint32_t lastFlag = 0, lastIdx = 0, bad = 0;
+        TRY(hipMemcpyAsync(&lastFlag, w.d_flagA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&lastIdx, w.d_idxA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&bad, w.d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipStreamSynchronize(c->stream));
+        if (bad) FAIL(c, PT_E_INVALID_ARG, "a triangle has a material index outside [0, %d)", n_mat);
+        w.nLights = lastFlag + lastIdx;
+        if (w.nLights) {
+            // rows in triangle order; the running sum rounds as a CPU loop over the triangles would (d_bad is free again: it receives the total)
+            TRY(hipMalloc(&w.lights, (size_t)w.nLights * 3 * sizeof(float4)));
+            float* const areas = (float*)w.d_flagB;   // free until the node flags are formed
+            hipLaunchKernelGGL(ptrepack::k_light_rows, dim3(launchGrid(n)), dim3(256), 0, c->stream, w.d_sorted, n, w.d_flagA, w.d_idxA, (float4*)w.lights, areas);
+            hipLaunchKernelGGL(ptrepack::k_light_sums, dim3(1), dim3(64), 0, c->stream, areas, (float4*)w.lights, w.nLights, (float*)w.d_bad);
+            TRY(hipMemcpyAsync(&w.lightSum, w.d_bad, 4, hipMemcpyDeviceToHost, c->stream));   // read after the final synchronisation
+        }
+    }
+    // ---- nodes: pair records, quad records, big-leaf rows
+    hipLaunchKernelGGL(ptrepack::k_flags, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_flagA, w.d_flagB);
+    TRY(ptrepack::exclusiveScan(c->stream, w.d_flagA, w.d_idxA, nn, &w.tmp, &w.tmpBytes));
+    TRY(ptrepack::exclusiveScan(c->stream, w.d_flagB, w.d_idxB, nn, &w.tmp, &w.tmpBytes));
+    uint32_t v[4] = {0, 0, 0, 0};
+    TRY(hipMemcpyAsync(&v[0], w.d_flagA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipMemcpyAsync(&v[1], w.d_idxA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipMemcpyAsync(&v[2], w.d_flagB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipMemcpyAsync(&v[3], w.d_idxB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipStreamSynchronize(c->stream));
+    const uint32_t nQuads = v[0] + v[1], nBig = v[2] + v[3];
+    if (nBig >= PT_LEAF_MAX_FIRST) FAIL(c, PT_E_BAD_BVH, "%u leaves of more than %d triangles", nBig, PT_LEAF_MAX_COUNT);
+    if (nn > 1) TRY(hipMalloc(&w.pairs, (size_t)(nn - 1) * 32));
+    if (nQuads) TRY(hipMalloc(&w.quads, (size_t)nQuads * 128));
+    if (nBig) TRY(hipMalloc(&w.big, (size_t)nBig * 8));
+    hipLaunchKernelGGL(ptrepack::k_records, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_idxA, w.d_idxB, w.d_flagB, (float4*)w.pairs,
+                       (float4*)w.quads, (uint2*)w.big);
+    TRY(hipMemcpyAsync(&w.root, w.bn, sizeof(w.root), hipMemcpyDeviceToHost, c->stream));
+    return PT_OK;
+}
+
+// The new scene replaces the old one (after the stream has finished everything repackOnDevice queued).
+static void adoptScene(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn) {
+    freeScene(c);
+    c->d_pairs = w.pairs; c->d_quads = w.quads; c->d_big = w.big; c->d_hot = w.hot; c->d_cold = w.cold; c->d_mats = w.mats; c->d_lights = w.lights;
+    w.pairs = w.quads = w.big = w.hot = w.cold = w.mats = w.lights = nullptr;
+    DevScene& sc = c->sc;
+    sc.pairs = (const float4*)c->d_pairs;
+    sc.quads = (const float4*)c->d_quads;
+    sc.big = (const uint2*)c->d_big;
+    sc.tri_hot = (const float4*)c->d_hot;
+    sc.tri_cold = (const float4*)c->d_cold;
+    sc.mats = (const float4*)c->d_mats;
+    sc.lights = (const float4*)c->d_lights;
+    sc.n_nodes = n ? (int32_t)nn : 0;
+    sc.n_tris = (int32_t)n;
+    sc.n_lights = (int32_t)w.nLights;
+    sc.light_total = w.lightSum;
+    for (int k = 0; k < 3; k++) { sc.root_min[k] = w.root.mn[k]; sc.root_max[k] = w.root.mx[k]; }
+    sc.root_left = w.root.left >= 0 ? w.root.left : w.root.first;
+    sc.root_count = w.root.left >= 0 ? 0 : w.root.count;
+    c->has_scene = true;
+}
+
 static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out,
                    int32_t node_capacity, int32_t* n_nodes, float* build_ms) {
     if (!c || n_mat < 0 || n_tri < 0 || (n_mat && !materials) || (n_tri && !triangles_in)) return PT_E_INVALID_ARG;
@@ -1231,30 +1149,7 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     const uint32_t n = (uint32_t)n_tri;
-    ptbuild::BNode root{};   // destination of a queued copy: declared before `w`, whose destructor waits for the stream
-    // Everything is built into buffers of this call; the context's scene is replaced only when all of it exists, and
-    // the destructor releases whatever is still held on any way out (error returns and exceptions alike).
-    struct Work {
-        pt_ctx* c;
-        ptbuild::Tri112 *d_in = nullptr, *d_sorted = nullptr;
-        ptbuild::Node32* d_nodes = nullptr;
-        ptbuild::BNode* bn = nullptr;
-        uint32_t *d_flagA = nullptr, *d_idxA = nullptr, *d_flagB = nullptr, *d_idxB = nullptr, *d_bad = nullptr;
-        void* tmp = nullptr;
-        void *pairs = nullptr, *quads = nullptr, *big = nullptr, *hot = nullptr, *cold = nullptr, *mats = nullptr, *lights = nullptr;   // the new scene
-        hipEvent_t ea = nullptr, eb = nullptr;
-        float lightSum = 0.0f;   // written by a copy queued on the stream
-        explicit Work(pt_ctx* ctx) : c(ctx) {}
-        ~Work() {
-            if (c->stream) (void)hipStreamSynchronize(c->stream);   // nothing queued may outlive the buffers (or this object)
-            void* all[] = {d_in, d_sorted, d_nodes, bn, d_flagA, d_idxA, d_flagB, d_idxB, d_bad, tmp, pairs, quads, big, hot, cold, mats, lights};
-            for (void* p : all) if (p) (void)hipFree(p);
-            if (ea) c->pool.push_back(ea);
-            if (eb) c->pool.push_back(eb);
-        }
-    } w(c);
-    size_t tmpBytes = 0;
-#define TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { FAIL(c, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s", #call, hipGetErrorString(_e)); } } while (0)
+    SceneWork w(c);
     if (n) {
         TRY(hipMalloc((void**)&w.d_in, (size_t)n * 112));
         TRY(hipMalloc((void**)&w.d_sorted, (size_t)n * 112));
@@ -1270,95 +1165,107 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
     w.d_in = nullptr;
     if ((int)levels > PT_STACK_TOTAL || 3 * (((int)levels + 1) / 2) > PT_STACK_TOTAL)
         FAIL(c, PT_E_BAD_BVH, "BVH depth %u exceeds the traversal stack (%d entries)", levels, PT_STACK_TOTAL);
-    const size_t flagsLen = std::max<size_t>(std::max<size_t>(n, nn), 1);
-    TRY(hipMalloc((void**)&w.d_flagA, flagsLen * 4));
-    TRY(hipMalloc((void**)&w.d_idxA, flagsLen * 4));
-    TRY(hipMalloc((void**)&w.d_flagB, flagsLen * 4));
-    TRY(hipMalloc((void**)&w.d_idxB, flagsLen * 4));
-    TRY(hipMalloc((void**)&w.d_bad, 4));
-    TRY(hipMemsetAsync(w.d_bad, 0, 4, c->stream));
-    if (n_mat) {
-        TRY(hipMalloc(&w.mats, (size_t)n_mat * 48));
-        TRY(hipMemcpyAsync(w.mats, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, c->stream));
-    }
-    // ---- triangles: hot / cold records, the light table
-    uint32_t nLights = 0;
-    if (n) {
-        TRY(hipMalloc(&w.hot, (size_t)n * 48));
-        TRY(hipMalloc(&w.cold, (size_t)n * 48));
-        hipLaunchKernelGGL(ptrepack::k_triangles, dim3(launchGrid(n)), dim3(256), 0, c->stream, w.d_sorted, n, (const float4*)w.mats, n_mat,
-                           (float4*)w.hot, (float4*)w.cold, w.d_flagA, w.d_bad);
-        TRY(ptrepack::exclusiveScan(c->stream, w.d_flagA, w.d_idxA, n, &w.tmp, &tmpBytes));
-        uint32_t lastFlag = 0, lastIdx = 0, bad = 0;
-        TRY(hipMemcpyAsync(&lastFlag, w.d_flagA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&lastIdx, w.d_idxA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&bad, w.d_bad, 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipStreamSynchronize(c->stream));
-        if (bad) FAIL(c, PT_E_INVALID_ARG, "a triangle has a material index outside [0, %d)", n_mat);
-        nLights = lastFlag + lastIdx;
-        if (nLights) {
-            // rows in triangle order; the running sum rounds as on the CPU path (d_bad is free again: it receives the total)
-            TRY(hipMalloc(&w.lights, (size_t)nLights * 3 * sizeof(float4)));
-            float* const areas = (float*)w.d_flagB;   // free until the node flags are formed
-            hipLaunchKernelGGL(ptrepack::k_light_rows, dim3(launchGrid(n)), dim3(256), 0, c->stream, w.d_sorted, n, w.d_flagA, w.d_idxA, (float4*)w.lights, areas);
-            hipLaunchKernelGGL(ptrepack::k_light_sums, dim3(1), dim3(64), 0, c->stream, areas, (float4*)w.lights, nLights, (float*)w.d_bad);
-            TRY(hipMemcpyAsync(&w.lightSum, w.d_bad, 4, hipMemcpyDeviceToHost, c->stream));   // read after the final synchronisation
-        }
-    }
-    // ---- nodes: pair records, quad records, big-leaf rows
-    uint32_t nQuads = 0, nBig = 0;
-    {
-        hipLaunchKernelGGL(ptrepack::k_flags, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_flagA, w.d_flagB);
-        TRY(ptrepack::exclusiveScan(c->stream, w.d_flagA, w.d_idxA, nn, &w.tmp, &tmpBytes));
-        TRY(ptrepack::exclusiveScan(c->stream, w.d_flagB, w.d_idxB, nn, &w.tmp, &tmpBytes));
-        uint32_t v[4] = {0, 0, 0, 0};
-        TRY(hipMemcpyAsync(&v[0], w.d_flagA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&v[1], w.d_idxA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&v[2], w.d_flagB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&v[3], w.d_idxB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipStreamSynchronize(c->stream));
-        nQuads = v[0] + v[1];
-        nBig = v[2] + v[3];
-        if (nBig >= PT_LEAF_MAX_FIRST) FAIL(c, PT_E_BAD_BVH, "%u leaves of more than %d triangles", nBig, PT_LEAF_MAX_COUNT);
-        if (nn > 1) TRY(hipMalloc(&w.pairs, (size_t)(nn - 1) * 32));
-        if (nQuads) TRY(hipMalloc(&w.quads, (size_t)nQuads * 128));
-        if (nBig) TRY(hipMalloc(&w.big, (size_t)nBig * 8));
-        hipLaunchKernelGGL(ptrepack::k_records, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_idxA, w.d_idxB, w.d_flagB, (float4*)w.pairs,
-                           (float4*)w.quads, (uint2*)w.big);
-    }
-    TRY(hipMemcpyAsync(&root, w.bn, sizeof(root), hipMemcpyDeviceToHost, c->stream));
+    const int rc = repackOnDevice(c, w, n, nn, materials, n_mat);
+    if (rc != PT_OK) return rc;
     if (w.eb) (void)hipEventRecord(w.eb, c->stream);
     if (triangles_out && n) TRY(hipMemcpyAsync(triangles_out, w.d_sorted, (size_t)n * 112, hipMemcpyDeviceToHost, c->stream));
     if (nodes_out) TRY(hipMemcpyAsync(nodes_out, w.d_nodes, (size_t)nn * 32, hipMemcpyDeviceToHost, c->stream));
     TRY(hipGetLastError());
     TRY(hipStreamSynchronize(c->stream));
-#undef TRY
     if (build_ms) {
         *build_ms = 0.0f;
         if (w.ea && w.eb) (void)hipEventElapsedTime(build_ms, w.ea, w.eb);
     }
-    // ---- success: the new scene replaces the old one
-    freeScene(c);
-    c->d_pairs = w.pairs; c->d_quads = w.quads; c->d_big = w.big; c->d_hot = w.hot; c->d_cold = w.cold; c->d_mats = w.mats; c->d_lights = w.lights;
-    w.pairs = w.quads = w.big = w.hot = w.cold = w.mats = w.lights = nullptr;
-    DevScene& sc = c->sc;
-    sc.pairs = (const float4*)c->d_pairs;
-    sc.quads = (const float4*)c->d_quads;
-    sc.big = (const uint2*)c->d_big;
-    sc.tri_hot = (const float4*)c->d_hot;
-    sc.tri_cold = (const float4*)c->d_cold;
-    sc.mats = (const float4*)c->d_mats;
-    sc.lights = (const float4*)c->d_lights;
-    sc.n_nodes = n ? (int32_t)nn : 0;
-    sc.n_tris = n_tri;
-    sc.n_lights = (int32_t)nLights;
-    sc.light_total = w.lightSum;
-    for (int k = 0; k < 3; k++) { sc.root_min[k] = root.mn[k]; sc.root_max[k] = root.mx[k]; }
-    sc.root_left = root.left >= 0 ? root.left : root.first;
-    sc.root_count = root.left >= 0 ? 0 : root.count;
-    c->has_scene = true;
+    adoptScene(c, w, n, nn);
     if (n_nodes) *n_nodes = (int32_t)nn;
     return PT_OK;
+}
+
+// pt_upload_scene: the host's arrays as Scene.CopyToDevice hands them over (Scene.cs:176-183).  They are copied to the GPU as they
+// are; the GPU checks the tree (nothing a kernel indexes with may be out of range: child indices, leaf ranges, every pair
+// referenced once, the leaves' triangle count, the depth), finds every node's depth by pointer jumping over the parent links,
+// and derives the device scene with the kernels pt_build_scene uses.  The host formats the message for the first offending node.
+static int uploadOne(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles, int32_t n_tri, const void* nodes, int32_t n_nodes) {
+    HIPCHECK(c, hipSetDevice(c->cfg.device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (n_tri == 0) n_nodes = 0;   // Accelerator.Build on an empty scene leaves a childless root (Accelerator.cs:120-125)
+    const uint32_t n = (uint32_t)n_tri, nn = (uint32_t)n_nodes;
+    SceneWork w(c);
+    if (nn == 0) {
+        if (n_mat) {
+            TRY(hipMalloc(&w.mats, (size_t)n_mat * 48));
+            TRY(hipMemcpyAsync(w.mats, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, c->stream));
+            TRY(hipStreamSynchronize(c->stream));
+        }
+        w.root.left = -1;
+        adoptScene(c, w, 0, 0);
+        return PT_OK;
+    }
+    if ((nn & 1u) == 0u) FAIL(c, PT_E_BAD_BVH, "node count %d is even: nodes are a root plus sibling pairs", n_nodes);
+    const HostNode* hn = (const HostNode*)nodes;
+    TRY(hipMalloc((void**)&w.d_sorted, (size_t)n * 112));
+    TRY(hipMalloc((void**)&w.d_nodes, (size_t)nn * 32));
+    TRY(hipMalloc((void**)&w.bn, (size_t)nn * sizeof(ptbuild::BNode)));
+    TRY(hipMalloc((void**)&w.d_parent, (size_t)nn * 4));
+    TRY(hipMalloc((void**)&w.d_refs, (size_t)(nn / 2 + 1) * 4));
+    for (int k = 0; k < 2; k++) { TRY(hipMalloc((void**)&w.d_anc[k], (size_t)nn * 4)); TRY(hipMalloc((void**)&w.d_dep[k], (size_t)nn * 4)); }
+    TRY(hipMalloc((void**)&w.d_check, sizeof(ptrepack::UploadCheck)));
+    TRY(hipMemcpyAsync(w.d_nodes, nodes, (size_t)nn * 32, hipMemcpyHostToDevice, c->stream));
+    TRY(hipMemcpyAsync(w.d_sorted, triangles, (size_t)n * 112, hipMemcpyHostToDevice, c->stream));
+    ptrepack::UploadCheck chk{};
+    chk.first_error = ~0ull;
+    TRY(hipMemcpyAsync(w.d_check, &chk, sizeof(chk), hipMemcpyHostToDevice, c->stream));
+    TRY(hipMemsetAsync(w.d_refs, 0, (size_t)(nn / 2 + 1) * 4, c->stream));
+    TRY(hipMemsetAsync(w.d_parent, 0, (size_t)nn * 4, c->stream));
+    hipLaunchKernelGGL(ptrepack::k_check_nodes, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.d_nodes, nn, n, w.d_parent, w.d_refs, w.d_check);
+    if (nn > 1) hipLaunchKernelGGL(ptrepack::k_check_refs, dim3(launchGrid(nn / 2)), dim3(256), 0, c->stream, w.d_refs, nn, w.d_check);
+    TRY(hipMemcpyAsync(&chk, w.d_check, sizeof(chk), hipMemcpyDeviceToHost, c->stream));
+    TRY(hipStreamSynchronize(c->stream));
+    if (chk.first_error != ~0ull) {
+        const int i = (int)(chk.first_error >> 3);
+        const HostNode& nd = hn[i];
+        switch ((int)(chk.first_error & 7ull)) {
+            case ptrepack::UPLOAD_LEAF_RANGE: FAIL(c, PT_E_BAD_BVH, "leaf %d references triangles [%d,%d) of %d", i, nd.leftFirst, nd.leftFirst + nd.count, n_tri);
+            case ptrepack::UPLOAD_CHILD_INDEX: FAIL(c, PT_E_BAD_BVH, "interior node %d has children at %d (need odd, > parent, < %d)", i, nd.leftFirst, n_nodes - 1);
+            case ptrepack::UPLOAD_UNREFERENCED: FAIL(c, PT_E_BAD_BVH, "node %d is not referenced by an earlier node", i);
+            default: FAIL(c, PT_E_BAD_BVH, "node pair %d is referenced twice", i);
+        }
+    }
+    if (chk.leaf_tris != (unsigned long long)n) FAIL(c, PT_E_BAD_BVH, "leaves cover %llu triangles, %d uploaded", chk.leaf_tris, n_tri);
+    // depth of every node: seven doublings over the parent links reach any depth the traversal stack allows
+    hipLaunchKernelGGL(ptrepack::k_depth_init, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.d_parent, nn, w.d_anc[0], w.d_dep[0]);
+    int cur = 0;
+    for (int round = 0; round < 7; round++) {
+        hipLaunchKernelGGL(ptrepack::k_depth_jump, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.d_anc[cur], w.d_dep[cur], w.d_anc[cur ^ 1], w.d_dep[cur ^ 1], nn);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(ptrepack::k_convert, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.d_nodes, w.d_anc[cur], w.d_dep[cur], nn, w.bn, w.d_check);
+    TRY(hipMemcpyAsync(&chk, w.d_check, sizeof(chk), hipMemcpyDeviceToHost, c->stream));
+    TRY(hipStreamSynchronize(c->stream));
+    const int depth = (int)chk.max_level + 1;
+    // the wide traversal pushes up to three entries on each of its (depth + 1) / 2 levels
+    if (chk.unresolved || depth > PT_STACK_TOTAL || 3 * ((depth + 1) / 2) > PT_STACK_TOTAL)
+        FAIL(c, PT_E_BAD_BVH, "BVH depth %s%d exceeds the traversal stack (%d entries)", chk.unresolved ? "> " : "", chk.unresolved ? 127 : depth, PT_STACK_TOTAL);
+    for (void** p : {(void**)&w.d_parent, (void**)&w.d_refs, (void**)&w.d_anc[0], (void**)&w.d_anc[1], (void**)&w.d_dep[0], (void**)&w.d_dep[1], (void**)&w.d_nodes}) {
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    const int rc = repackOnDevice(c, w, n, nn, materials, n_mat);
+    if (rc != PT_OK) return rc;
+    TRY(hipGetLastError());
+    TRY(hipStreamSynchronize(c->stream));
+    adoptScene(c, w, n, nn);
+    return PT_OK;
+}
+#undef TRY
+
+static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles, int32_t n_tri, const void* nodes, int32_t n_nodes) {
+    if (!c) return PT_E_INVALID_ARG;
+    if (n_mat < 0 || n_tri < 0 || n_nodes < 0 || (n_mat && !materials) || (n_tri && !triangles) || (n_nodes && !nodes)) FAIL(c, PT_E_INVALID_ARG, "pt_upload_scene: bad counts or null arrays");
+    if (n_tri > 0 && n_nodes == 0) FAIL(c, PT_E_BAD_BVH, "%d triangles but no nodes", n_tri);
+    // several GPUs: each takes its own copy of the arrays and derives its own replica, all at once
+    if (c->group) return c->group->all(c, [&](pt_ctx* m) { return uploadOne(m, materials, n_mat, triangles, n_tri, nodes, n_nodes); });
+    return uploadOne(c, materials, n_mat, triangles, n_tri, nodes, n_nodes);
 }
 
 int pt_get_stats(pt_ctx* c, pt_stats* out) {

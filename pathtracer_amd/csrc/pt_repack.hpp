@@ -121,6 +121,88 @@ __global__ void __launch_bounds__(256) k_records(const BNode* nodes, uint32_t n_
     }
 }
 
+// ---- a tree that arrives from the host (pt_upload_scene): Node[] as Accelerator.Build leaves it (Accelerator.cs:113-177)
+// What the checks guarantee: no kernel can index out of bounds through these nodes, every node hangs below the root exactly
+// once, and the leaves hold as many triangles as were uploaded.
+using ptbuild::Node32;
+enum { UPLOAD_LEAF_RANGE = 1, UPLOAD_CHILD_INDEX = 2, UPLOAD_UNREFERENCED = 3, UPLOAD_TWICE = 4 };
+struct UploadCheck {
+    unsigned long long first_error;   // (node index << 3 | kind) of the lowest offending node, ~0 if none
+    unsigned long long leaf_tris;     // triangles in all leaves
+    uint32_t max_level;               // deepest node (root 0)
+    uint32_t unresolved;              // nodes whose depth the jumps did not reach: deeper than 127
+};
+__global__ void __launch_bounds__(256) k_check_nodes(const Node32* nodes, uint32_t n_nodes, uint32_t n_tris, uint32_t* parent, uint32_t* refs, UploadCheck* chk) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t tris = 0;
+    if (i < n_nodes) {
+        const Node32 nd = nodes[i];
+        if (nd.count > 0) {
+            if (nd.leftFirst < 0 || (long long)nd.leftFirst + nd.count > (long long)n_tris) atomicMin(&chk->first_error, ((unsigned long long)i << 3) | UPLOAD_LEAF_RANGE);
+            else tris = (uint32_t)nd.count;
+        } else {
+            const long long l = nd.leftFirst;
+            if (l <= (long long)i || (l & 1) == 0 || l + 1 >= (long long)n_nodes) atomicMin(&chk->first_error, ((unsigned long long)i << 3) | UPLOAD_CHILD_INDEX);
+            else {
+                atomicAdd(&refs[l >> 1], 1u);      // pair (l - 1) / 2
+                parent[l] = parent[l + 1] = i;
+            }
+        }
+    }
+    // one atomic per block: a single counter word takes them one after the other
+    __shared__ unsigned long long s_total;
+    if (threadIdx.x == 0) s_total = 0ull;
+    __syncthreads();
+    unsigned long long total = tris;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if ((threadIdx.x & 63u) == 0u && total) atomicAdd(&s_total, total);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_total) atomicAdd(&chk->leaf_tris, s_total);
+}
+__global__ void __launch_bounds__(256) k_check_refs(const uint32_t* refs, uint32_t n_nodes, UploadCheck* chk) {
+    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;   // nodes 2 * pair + 1 and 2 * pair + 2
+    if (2u * pair + 2u >= n_nodes) return;
+    const uint32_t r = refs[pair];
+    if (r != 1u) atomicMin(&chk->first_error, ((unsigned long long)(2u * pair + 1u) << 3) | (r == 0u ? UPLOAD_UNREFERENCED : UPLOAD_TWICE));
+}
+// depth by pointer jumping: after k doublings dep[i] is the distance to anc[i], the 2^k-th ancestor (or the root)
+__global__ void __launch_bounds__(256) k_depth_init(const uint32_t* parent, uint32_t n_nodes, uint32_t* anc, uint32_t* dep) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    anc[i] = i ? parent[i] : 0u;
+    dep[i] = i ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_depth_jump(const uint32_t* anc_in, const uint32_t* dep_in, uint32_t* anc_out, uint32_t* dep_out, uint32_t n_nodes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t a = anc_in[i];
+    dep_out[i] = dep_in[i] + dep_in[a];
+    anc_out[i] = anc_in[a];
+}
+// the host's node in the form the record kernels read (children side by side at `left`, depth in `level`)
+__global__ void __launch_bounds__(256) k_convert(const Node32* nodes, const uint32_t* anc, const uint32_t* dep, uint32_t n_nodes, BNode* out, UploadCheck* chk) {
+    __shared__ uint32_t s_max;
+    if (threadIdx.x == 0) s_max = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nodes) {
+        const Node32 nd = nodes[i];
+        BNode b{};
+        for (int a = 0; a < 3; a++) { b.mn[a] = nd.mn[a]; b.mx[a] = nd.mx[a]; }
+        const bool leaf = nd.count > 0;
+        b.first = leaf ? nd.leftFirst : 0;
+        b.count = leaf ? nd.count : 0;
+        b.left = leaf ? -1 : nd.leftFirst;
+        b.axis = leaf ? 0 : -nd.count - 1;          // the split axis travels in an interior node's negative count (Accelerator.cs:158-159)
+        b.level = dep[i];
+        out[i] = b;
+        if (anc[i] != 0u) atomicOr(&chk->unresolved, 1u);
+        atomicMax(&s_max, dep[i]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&chk->max_level, s_max);   // one atomic per block: a single counter word takes them one after the other
+}
+
 inline hipError_t exclusiveScan(hipStream_t stream, const uint32_t* in, uint32_t* out, size_t n, void** tmp, size_t* tmpBytes) {
     size_t need = 0;
     hipError_t e = rocprim::exclusive_scan(nullptr, need, in, out, 0u, n, rocprim::plus<uint32_t>(), stream);

@@ -44,7 +44,7 @@ def main():
         print(f"  GPU build: {ms:.1f} ms on the device, {wall * 1e3:.0f} ms with transfers and host copies; {gn.size} nodes, {tris.size / ms / 1e3:.1f} Mtris/s", flush=True)
     t0 = time.perf_counter()
     wf.upload_scene(mats, tris, nodes)
-    print(f"  pt_upload_scene of host-built arrays (CPU repack + transfers): {(time.perf_counter() - t0) * 1e3:.0f} ms", flush=True)
+    print(f"  pt_upload_scene of host-built arrays (transfers, checks and repack on the device): {(time.perf_counter() - t0) * 1e3:.0f} ms", flush=True)
     for it in range(2):
         t0 = time.perf_counter()
         ms = wf.build_scene(mats, tris)
