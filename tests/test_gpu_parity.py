@@ -518,6 +518,37 @@ def test_bad_bvh_rejected(pa, ob, bundled):
     bad["left_first"][leaf] = tris.size  # leaf range out of bounds
     with pytest.raises(pa.PtError):
         wf.upload_scene(mats, tris, bad)
+    # two interior nodes that claim the same pair of children (and leave another pair to nobody)
+    inner = np.nonzero(nodes["count"] <= 0)[0]
+    bad = nodes.copy()
+    bad["left_first"][inner[2]] = bad["left_first"][inner[1]] if bad["left_first"][inner[1]] > inner[2] else bad["left_first"][inner[3]]
+    with pytest.raises(pa.PtError) as e:
+        wf.upload_scene(mats, tris, bad)
+    assert e.value.code == -5 and ("referenced" in str(e.value))
+    # a leaf that forgets one of its triangles
+    bad = nodes.copy()
+    two = np.nonzero(bad["count"] >= 2)[0][0]
+    bad["count"][two] -= 1
+    with pytest.raises(pa.PtError) as e:
+        wf.upload_scene(mats, tris, bad)
+    assert e.value.code == -5 and "leaves cover" in str(e.value)
+    # chains of sibling pairs: 40 levels are fine, 100 exceed the traversal stack, 140 exceed what the depth search resolves
+    from pathtracer_amd.types import NODE
+    for levels, ok in ((40, True), (100, False), (140, False)):
+        chain = np.zeros(2 * levels + 1, NODE)
+        chain["min"], chain["max"] = (-1, -1, -1), (1, 1, 1)
+        for k in range(levels):                      # node 2k is interior (the root for k = 0): children 2k+1 (a leaf) and 2k+2
+            chain["left_first"][2 * k], chain["count"][2 * k] = 2 * k + 1, -1
+            chain["left_first"][2 * k + 1], chain["count"][2 * k + 1] = k, 1
+        chain["left_first"][2 * levels], chain["count"][2 * levels] = levels, 1
+        if ok:
+            other = pa.Wavefront()
+            other.upload_scene(mats, tris[:levels + 1], chain)
+            other.close()
+        else:
+            with pytest.raises(pa.PtError) as e:
+                wf.upload_scene(mats, tris[:levels + 1], chain)
+            assert e.value.code == -5 and "depth" in str(e.value)
     badt = tris.copy()
     badt["material"][5] = 9999
     with pytest.raises(pa.PtError):
