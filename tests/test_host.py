@@ -285,6 +285,36 @@ def test_c_abi_exports_every_declared_symbol():
     assert set(_native.PT_HIP_SYMBOLS) == set(re.findall(r"\b(pt_[a-z_0-9]+)\s*\(", re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pt_hip.h")).read(), flags=re.S)))
 
 
+def test_csharp_shim_matches_the_header():
+    """The C# shim cannot be compiled here, so what can drift is checked as text: the files under bindings/csharp are the code
+    blocks of INTEGRATION.md; every DllImport names an exported function and takes as many parameters as the C declaration; the
+    Config struct has pt_config's fields in pt_config's order."""
+    from pathtracer_amd import _native
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    native = open(os.path.join(ROOT, "bindings", "csharp", "Native.cs")).read()
+    for name in os.listdir(os.path.join(ROOT, "bindings", "csharp")):
+        body = open(os.path.join(ROOT, "bindings", "csharp", name)).read().split("\n", 2)[2]      # below the two header lines
+        for line in (l for l in body.splitlines() if l.strip()):
+            assert line in doc, f"bindings/csharp/{name} has a line INTEGRATION.md does not: run tools/extract_csharp.py\n{line}"
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pt_hip.h")).read(), flags=re.S)
+    c_params = {m.group(1): len([a for a in m.group(2).split(",") if a.strip() and a.strip() != "void"])
+                for m in re.finditer(r"\b(pt_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", header)}
+    imports = re.findall(r"\[DllImport\(Lib\)\]\s*public static extern \w+ (pt_[a-z_0-9]+)\(([^)]*)\)", native, flags=re.S)
+    assert len(imports) >= 12
+    lib = ctypes.CDLL(os.path.join(PKG, "libpt_hip.so"))
+    for fn, params in imports:
+        assert hasattr(lib, fn), fn
+        assert len([a for a in params.split(",") if a.strip()]) == c_params[fn], fn
+    struct = re.search(r"public struct Config\s*\{(.*?)\n        \}", native, flags=re.S).group(1)
+    struct = re.sub(r"//[^\n]*", "", struct)
+    fields = []
+    for decl in re.findall(r"public int(\[\])? ([^;]*);", struct):
+        fields += [f.strip() for f in decl[1].split(",")]
+    snake = lambda f: re.sub(r"(?<!^)([A-Z])", r"_\1", f).lower()
+    assert [snake(f) for f in fields] == [n for n, _ in _native.pt_config._fields_]
+    assert "SizeConst = 5" in native and ctypes.sizeof(_native.pt_config) == 4 * (len(fields) - 1 + 5)
+
+
 def test_headers_are_plain_c(tmp_path):
     """include/*.h compile as C99 with -pedantic, and the C example builds against both libraries."""
     src = tmp_path / "h.c"
