@@ -97,6 +97,10 @@ struct pt_ctx {
     // idle lanes a traversal wave collects before it fetches new rays: camera rays of a tile finish together, so waiting for
     // most of the wave costs little and saves refills; scattered rays finish at very different times
     int refill_primary = 48, refill_bounce = 40;
+    // A tree that does not fit L2 (1M small triangles and up) means camera rays that part ways inside it: such scenes gain 3-4 % from
+    // waves that fetch camera rays earlier (at 32 idle lanes) and from camera rays queued group by group; scenes whose tree stays in
+    // L2 lose 1-4 % with either.  An explicit PT_OPT_REFILL_PRIMARY wins.
+    bool large_tree = false, refill_primary_set = false;
     uint64_t local_pixels = 0;
     int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
     void* scratch_dev = nullptr;   // this device's copy of the fixed staging array (pt_trace_closest_noalloc)
@@ -508,7 +512,7 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
             c->grid_extend = c->num_cu * std::min(value ? value : 7, c->fit_extend);
             c->grid_connect = c->num_cu * std::min(value ? value : 7, c->fit_connect);
             break;
-        case PT_OPT_REFILL_PRIMARY: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_primary = value; break;
+        case PT_OPT_REFILL_PRIMARY: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_primary = value; c->refill_primary_set = true; break;
         case PT_OPT_REFILL_BOUNCE: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_bounce = value; break;
         case PT_OPT_SAMPLES_PER_BATCH: if (value < 0) FAIL(c, PT_E_INVALID_ARG, "samples_per_batch %d", value); c->cfg.samples_per_batch = value; break;
         default: FAIL(c, PT_E_INVALID_ARG, "unknown option %d", key);
@@ -630,6 +634,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
         const bool dense = (c->width % 8 == 0) && (c->height % 8 == 0);
         // dense batches: every slot is a path, and shade of bounce 0 stores each path's first value itself
         rp.plane_fresh = (dense && !generate_only) ? 1 : 0;
+        rp.group_major = (!generate_only && c->large_tree) ? 1 : 0;
         if (!rp.plane_fresh) HIPCHECK(c, hipMemsetAsync(c->q.plane, 0, (size_t)total * sizeof(float4), c->stream));
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, dense ? total : 0u, 0ull);
         {
@@ -649,7 +654,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             rp.last_bounce = (b == max_bounces - 1) ? 1 : 0;
             {
                 StageTimer t(c, b == 0 ? 4 : 1);
-                launchExtend(c, stats, cur, (uint32_t)(b == 0 ? c->refill_primary : c->refill_bounce));
+                launchExtend(c, stats, cur, (uint32_t)(b == 0 ? ((c->large_tree && !c->refill_primary_set) ? 32 : c->refill_primary) : c->refill_bounce));
                 c->host_stats.extend_launches++;
             }
             if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_connected, 0)); connectPending = false; }
@@ -1035,7 +1040,7 @@ struct SceneWork {
     hipEvent_t ea = nullptr, eb = nullptr;
     float lightSum = 0.0f;     // written by copies queued on the stream
     ptbuild::BNode root{};
-    uint32_t nLights = 0;
+    uint32_t nLights = 0, nQuads = 0;
     explicit SceneWork(pt_ctx* ctx) : c(ctx) {}
     SceneWork(const SceneWork&) = delete;
     SceneWork& operator=(const SceneWork&) = delete;
@@ -1099,6 +1104,7 @@ static int repackOnDevice(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn, cons
     TRY(hipMemcpyAsync(&v[3], w.d_idxB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
     TRY(hipStreamSynchronize(c->stream));
     const uint32_t nQuads = v[0] + v[1], nBig = v[2] + v[3];
+    w.nQuads = nQuads;
     if (nBig >= PT_LEAF_MAX_FIRST) FAIL(c, PT_E_BAD_BVH, "%u leaves of more than %d triangles", nBig, PT_LEAF_MAX_COUNT);
     if (nn > 1) TRY(hipMalloc(&w.pairs, (size_t)(nn - 1) * 32));
     if (nQuads) TRY(hipMalloc(&w.quads, (size_t)nQuads * 128));
@@ -1126,6 +1132,7 @@ static void adoptScene(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn) {
     sc.n_tris = (int32_t)n;
     sc.n_lights = (int32_t)w.nLights;
     sc.light_total = w.lightSum;
+    c->large_tree = (size_t)w.nQuads * 128 > ((size_t)32 << 20);
     for (int k = 0; k < 3; k++) { sc.root_min[k] = w.root.mn[k]; sc.root_max[k] = w.root.mx[k]; }
     sc.root_left = w.root.left >= 0 ? w.root.left : w.root.first;
     sc.root_count = w.root.left >= 0 ? 0 : w.root.count;

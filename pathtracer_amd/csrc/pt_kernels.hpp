@@ -40,6 +40,7 @@ struct RenderParams {
     int32_t rng_mode, nee;
     int32_t plane_fresh;       // the batch's planes were not cleared: shade of bounce 0 stores every path's first value
     int32_t bounce, last_bounce;
+    int32_t group_major;       // order of the camera rays in the queue (the birth index is sample-major either way)
 };
 
 struct Queues {
@@ -65,8 +66,14 @@ __global__ void __launch_bounds__(PT_BLOCK) k_generate(RenderParams rp, Queues q
     uint32_t pixel = 0, gidx = 0;
     uint32_t sample = 0, slot = 0;
     if (valid) {
-        sample = k / rp.slots;
-        slot = k - sample * rp.slots;
+        if (rp.group_major) {   // the samples of one 8x8 pixel group follow each other: a wave's range of the queue stays inside one group
+            const uint32_t per = 64u * rp.samples, group = k / per, within = k - group * per;
+            sample = within >> 6;
+            slot = group * 64u + (within & 63u);
+        } else {
+            sample = k / rp.slots;
+            slot = k - sample * rp.slots;
+        }
         valid = pixelOfSlot(slot, rp.width, rp.height, rp.rank, rp.world, &pixel, &gidx);
     }
     f3 origin = mk3(0, 0, 0), dir = mk3(0, 0, 0);
@@ -88,7 +95,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_generate(RenderParams rp, Queues q
     }
     const uint32_t out = DENSE ? k : waveAppend(valid, &ctl->count[0]);
     if (valid) {
-        ntStore(&q.o[0][out], make_float4(origin.x, origin.y, origin.z, __uint_as_float(k)));
+        ntStore(&q.o[0][out], make_float4(origin.x, origin.y, origin.z, __uint_as_float(sample * rp.slots + slot)));   // birth: sample-major, the planes' index
         ntStore(&q.d[0][out], make_float4(dir.x, dir.y, dir.z, __uint_as_float(1u)));
         // the throughput of a fresh path is (1,1,1,1) (generate.glsl:199): shade knows that at bounce 0, so it is not stored
     }
