@@ -649,6 +649,12 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
         // stream of its own beside extend(b + 1), whose tail it fills.  Per-stage timing keeps the stages apart on one stream.
         const bool beside = c->cfg.stage_timing != 1;
         bool connectPending = false;
+        // a way out of this loop with a connect still running on its stream (a failed call below) waits for it: everything else
+        // in the library orders itself after the context's main stream only
+        struct Join {
+            pt_ctx* c; bool* pending;
+            ~Join() { if (*pending) (void)hipStreamSynchronize(c->stream_connect); }
+        } join{c, &connectPending};
         for (int b = 0; b < max_bounces; b++) {
             rp.bounce = b;
             rp.last_bounce = (b == max_bounces - 1) ? 1 : 0;
@@ -681,7 +687,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             }
             cur ^= 1;
         }
-        if (connectPending) HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_connected, 0));
+        if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_connected, 0)); connectPending = false; }
         hipLaunchKernelGGL(k_resolve, dim3(launchGrid(c->slots)), dim3(PT_BLOCK), 0, c->stream, c->d_sum, (const float4*)c->q.plane, c->slots, ns);
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, (unsigned long long)c->local_pixels * ns);
     }

@@ -51,7 +51,7 @@ __device__ __forceinline__ f4 operator+(f4 a, f4 b) { return mk4(a.x + b.x, a.y 
 // pairs:    one 64-byte record per sibling pair = the host's Node[2k+1], Node[2k+2] (Node.cs:5-10),
 //           64-byte aligned so one traversal step is one cache line.  The boxes are verbatim; the
 //           leftFirst word of each node is replaced at upload by the node's traversal entry (see
-//           packLeaf), so a step forms no entries.
+//           ptrepack::leafEntry), so a step forms no entries.
 // quads:    one 128-byte record per interior node at an even depth: the boxes of its (up to four)
 //           grandchildren — a child that is a leaf stands for itself — as six float4 columns
 //           (min x, min y, min z, max x, max y, max z), then the four traversal entries and 16
@@ -342,16 +342,6 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 #ifndef PT_GRAB_SWITCH
 #define PT_GRAB_SWITCH 1024u   // rays per wave above which a launch counts as large
 #endif
-
-// Entry of a leaf with triangles [first, first+count); `bigIndex` is its row in the side table
-// when it does not fit the packed form.  Used by the upload code (host side).
-static inline bool leafFitsPacked(int32_t first, int32_t count) {
-    return count <= PT_LEAF_MAX_COUNT && (uint32_t)first < PT_LEAF_MAX_FIRST;
-}
-static inline uint32_t packLeaf(int32_t first, int32_t count, uint32_t bigIndex) {
-    if (leafFitsPacked(first, count)) return PT_LEAF_FLAG | ((uint32_t)(count - 1) << 27) | (uint32_t)first;
-    return PT_LEAF_FLAG | (15u << 27) | bigIndex;
-}
 
 // Source: struct with
 //   void load(uint32_t i, f3* o, f3* d, float* tlimit) const   — ray i of the queue
