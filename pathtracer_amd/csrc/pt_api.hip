@@ -442,12 +442,7 @@ static int impl_create_single(const pt_config* cfg, pt_ctx** out) {
     c->cfg = *cfg;
     hipError_t e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) {
-        // lowest priority: extend -> shade is the frame's critical path, connect takes what that leaves (1 % of a frame against equal priorities)
-        int least = 0, greatest = 0;
-        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->stream_connect, hipStreamNonBlocking, least);
-    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_connect, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_shaded, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_connected, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctl, sizeof(Ctl));
