@@ -199,7 +199,9 @@ int pt_set_option(pt_ctx* ctx, int32_t key, int32_t value);
 int pt_accum_device(pt_ctx* ctx, void** device_ptr, uint64_t* n_slots_padded, uint32_t* samples);
 int pt_assemble_tiles(pt_ctx* ctx, const void* gathered_device, int32_t world, uint32_t samples, float* rgba_host);
 
-/* Stream the context enqueues on (hipStream_t as void*), for callers that order their own work after it. */
+/* Stream the context enqueues on (hipStream_t as void*), for callers that order their own work after it.  pt_render also uses a
+ * second, internal stream (the shadow rays of a bounce are traced beside the next bounce's rays); it is joined into this one before
+ * pt_render returns, so work ordered after this stream is ordered after all of a render call. */
 int pt_stream(pt_ctx* ctx, void** stream);
 
 #ifdef __cplusplus
