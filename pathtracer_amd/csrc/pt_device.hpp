@@ -256,6 +256,18 @@ __device__ __forceinline__ bool slabTest(float mnx, float mny, float mnz, float 
     return hit;
 }
 
+// The two distances of slabTest<false> without its verdict (the wide step folds the verdict into its order key).
+__device__ __forceinline__ void slabRange(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, f3 o, f3 inv, float* tmin, float* tmax) {
+    float t1 = (mnx - o.x) * inv.x;
+    float t2 = (mxx - o.x) * inv.x;
+    float t3 = (mny - o.y) * inv.y;
+    float t4 = (mxy - o.y) * inv.y;
+    float t5 = (mnz - o.z) * inv.z;
+    float t6 = (mxz - o.z) * inv.z;
+    *tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    *tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+}
+
 // Triangle.cs:15-47 with edge1 = V2-V1 and edge2 = V3-V1 taken from the hot record (the
 // same two subtractions, done once at upload).  Returns dist > 0 acceptance; the caller
 // compares against its current best.
@@ -389,9 +401,14 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
     uint2 spill[PT_STACK_SPILL];
     uint2* const mystack = lstack + lane;
 
-    // makes `e` current; for a leaf also sets [leafJ, leafEnd)
+    // makes `e` current.  A leaf's range [leafJ, leafEnd) is unpacked when its first leaf phase begins (leafEnd == 0 until then: every
+    // real range ends at 1 or later), so interior steps — most entries are interior — do not pay for it.
     auto enter = [&](uint32_t e) {
         cur = e;
+        leafEnd = 0;
+    };
+    auto unpackLeaf = [&]() {
+        const uint32_t e = cur;
         const uint32_t low = e & (PT_LEAF_MAX_FIRST - 1u), cm1 = (e >> 27) & 15u;
         leafJ = (int32_t)low;
         leafEnd = (int32_t)(low + cm1 + 1u);
@@ -533,11 +550,16 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
 #else
 #define PT_QUAD_CHILD(K, E, C, SLOT)                                                                          \
                     {                                                                                          \
-                        float tm;                                                                              \
-                        bool h = slabTest<false>(mnx.C, mny.C, mnz.C, mxx.C, mxy.C, mxz.C, o, inv, &tm);       \
-                        h = h && (ANYHIT ? tm < tlimit : !(tm > best));                                        \
+                        float tm, tx;                                                                          \
+                        slabRange(mnx.C, mny.C, mnz.C, mxx.C, mxy.C, mxz.C, o, inv, &tm, &tx);                 \
                         const int32_t tb = __float_as_int(tm);   /* negative distances (and -0) clamp to +0 */ \
-                        K = h ? (((uint32_t)(tb > 0 ? tb : 0) & ~3u) | SLOT) : PT_KEY_MISS;                    \
+                        const int32_t t0 = tb > 0 ? tb : 0;                                                    \
+                        /* Box.cs:51-79 passes when tx > 0 and tm < tx; with t0 = max(tm, +0) that is t0 < tx  \
+                           (t0 >= 0 makes tx positive, tm <= t0).  The best distance is positive, so           \
+                           "not beyond the best hit" reads the same on t0 as on tm. */                          \
+                        const float tc = __int_as_float(t0);                                                   \
+                        const bool h = tc < tx && (ANYHIT ? tm < tlimit : !(tc > best));                       \
+                        K = h ? (((uint32_t)t0 & ~3u) | SLOT) : PT_KEY_MISS;                                   \
                     }
                     PT_QUAD_CHILD(k0, e0, x, 0u)
                     PT_QUAD_CHILD(k1, e1, y, 1u)
@@ -617,6 +639,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             float2* const resUv = (float2*)(leafq + 64);                    // [64] its barycentrics
             uint32_t* const ownerOf = (uint32_t*)(leafq + 128);             // [64] owner lane of each dealt triangle
             const bool owner = (int32_t)cur < 0;
+            if (owner && leafEnd == 0) unpackLeaf();
             const uint32_t left = owner ? (uint32_t)(leafEnd - leafJ) : 0u;
             const uint32_t cnt = left < 64u ? left : 64u;
             const uint32_t incl = waveInclusiveScan(cnt);
