@@ -53,6 +53,7 @@ def traffic_entry(vals, source, command):
 def main():
     tag, run, bench_name = sys.argv[1], sys.argv[2], sys.argv[3]
     out, prof = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+    previous = json.load(open(os.path.join(prof, "traffic.json"))) if os.path.exists(os.path.join(prof, "traffic.json")) else {}
     traffic = {}
     for w, args in (("bundled", ""), ("c3", " --workload c3 --steps 1")):
         summary = os.path.join(out, f"{run}_pmc_{w}_summary.txt")
@@ -68,6 +69,11 @@ def main():
         if w in traffic:    # the line was printed with the previous round's traffic.json
             d["roofline"]["traffic"] = traffic[w]["extend_hbm_bytes_per_launch"]
             d["roofline"]["traffic_source"] = traffic[w]["source"] + " (committed PMC passes of the same command, not measured by this run)"
+            # the line's cross-check was printed against the previous passes' instruction count: restate it against these
+            ratio, before = d["roofline"].get("issue_model_over_sq_insts_valu"), previous.get(w, {}).get("sq_insts_valu_per_launch")
+            if ratio and before:
+                d["roofline"]["issue_model_over_sq_insts_valu"] = ratio * before / traffic[w]["sq_insts_valu_per_launch"]
+                d["roofline"]["valu_busy_pmc"] = traffic[w]["valu_busy"]
         name = f"{tag}_bench_bundled.json" if w == "bundled" else f"{tag}_cfg_{w}.json"
         open(os.path.join(prof, name), "w").write(json.dumps(d) + "\n")
     table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_configs_md.py"), cfg], capture_output=True, text=True, check=True).stdout
