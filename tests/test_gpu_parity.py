@@ -570,6 +570,31 @@ def test_bad_bvh_rejected(pa, ob, bundled):
     wf.close()
 
 
+def test_replacing_scenes_does_not_leak_device_memory(pa, bundled):
+    """A host that re-uploads or rebuilds its scene over and over (key P in the reference, Game.cs:169-180) must get the memory of
+    the scene it replaces back: 60 replacements by either entry point, refused ones among them, leave the device's free memory
+    where it was."""
+    import torch
+    mats, tris, nodes, refs = bundled.arrays(references=True)
+    wf = pa.Wavefront(nee=True, rng_mode=1)
+    wf.upload_scene(mats, tris, nodes)
+    wf.build_scene(mats, refs)
+    wf.synchronize()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    badt = tris.copy()
+    badt["material"][7] = 12345
+    for k in range(20):
+        wf.upload_scene(mats, tris, nodes)
+        wf.build_scene(mats, refs)
+        with pytest.raises(pa.PtError):
+            (wf.upload_scene if k & 1 else wf.build_scene)(mats, badt, *(() if not (k & 1) else (nodes,)))
+    wf.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), f"{(free0 - free1) >> 20} MiB of device memory did not come back"
+    wf.close()
+
+
 def test_context_lifecycle(pa, bundled, cornell):
     """One context through the sequence a host goes through — wrong-order calls are refused, resizing and replacing
     the scene leave no stale state: every image equals a fresh context's."""
