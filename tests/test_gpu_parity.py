@@ -595,6 +595,32 @@ def test_replacing_scenes_does_not_leak_device_memory(pa, bundled):
     wf.close()
 
 
+def test_contexts_and_resizes_do_not_leak_device_memory(pa, bundled):
+    """Contexts created and destroyed, and one context resized back and forth between frames (Game.Resize, Game.cs:138-151): the
+    device's free memory ends where it began."""
+    import torch
+    mats, tris, nodes = bundled.arrays()
+
+    def one_context(sizes):
+        wf = pa.Wavefront(nee=True, rng_mode=1)
+        wf.upload_scene(mats, tris, nodes)
+        for w, h in sizes:
+            wf.allocate(w, h)
+            wf.invoke(bundled_view(bundled, w, h), spp=2, max_bounces=3)
+            wf.read_image()
+        wf.close()
+
+    one_context([(64, 64)])
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(10):
+        one_context([(64, 64)])
+    one_context([(640, 360), (64, 48), (1280, 720), (90, 50), (640, 360)] * 3)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), f"{(free0 - free1) >> 20} MiB of device memory did not come back"
+
+
 def test_context_lifecycle(pa, bundled, cornell):
     """One context through the sequence a host goes through — wrong-order calls are refused, resizing and replacing
     the scene leave no stale state: every image equals a fresh context's."""
