@@ -33,6 +33,10 @@ namespace PathTracer
         [DllImport(Lib)] public static extern int pt_trace_closest(IntPtr ctx, float[] originDirection, int n, int[] tri, float[] t, float[] uv);
         [DllImport(Lib)] public static extern int pt_build_bvh(IntPtr ctx, Triangle[] trianglesIn, int nTriangles, Triangle[] trianglesOut,
                                                                Node[] nodesOut, int nodeCapacity, out int nNodes, out float buildMs);
+        [DllImport(Lib)] public static extern int pt_build_scene(IntPtr ctx, Material[] materials, int nMaterials, Triangle[] trianglesIn, int nTriangles,
+                                                                 Triangle[] trianglesOut, Node[] nodesOut, int nodeCapacity, out int nNodes, out float buildMs);
+        [DllImport(Lib)] public static extern int pt_trace_closest_noalloc(IntPtr ctx, float[] originDirection, int n, int[] tri, float[] t, float[] uv);
+        [DllImport(Lib)] public static extern int pt_trace_occluded(IntPtr ctx, float[] originDirection, float[] tmax, int n, byte[] occluded);
         [DllImport(Lib)] public static extern int pt_set_option(IntPtr ctx, int key, int value);
 
         public static void Check(IntPtr ctx, int status)
