@@ -179,4 +179,25 @@ def test_config3_soup_render_against_the_oracle(pa, ob):
     for k in ["extend_rays", "shadow_rays", "extend_steps", "extend_tris", "shadow_steps", "shadow_tris"]:
         assert st[k] == ost[k], (k, st[k], ost[k])
     assert np.array_equal(bits(img), bits(osum / np.float32(spp)))
+    # at the configuration's full size (1920x1080; 6 of its 64 spp): the image is the same bits however the samples are batched
+    # or split over calls, the ray counts are equal, nothing overflows
+    w, h = 1920, 1080
+    fs, _ = o.camera((0, 0, 120), (0, 0, 0), w, h, use_scene=False, frames=1, samples=1)
+    imgs, counts = [], []
+    for batch, calls in [(6, [6]), (4, [6]), (0, [2, 4])]:
+        wf.set_option(5, batch)
+        wf.allocate(w, h)
+        wf.reset_stats()
+        f = fs.copy()
+        for n in calls:
+            wf.invoke(f, spp=n, max_bounces=4)
+            f["frames"] += n
+            f["samples"] += n
+        imgs.append(wf.read_image())
+        st = wf.stats()
+        counts.append((st["paths"], st["extend_rays"], st["shadow_rays"], st["extend_steps"], st["shadow_steps"]))
+        assert st["stack_overflows"] == 0
+    assert counts[0][0] == 6 * w * h and counts[0] == counts[1] == counts[2]
+    assert np.isfinite(imgs[0]).all() and (imgs[0] >= 0).all()
+    assert np.array_equal(bits(imgs[1]), bits(imgs[0])) and np.array_equal(bits(imgs[2]), bits(imgs[0]))
     wf.close()
