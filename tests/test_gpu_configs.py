@@ -155,6 +155,26 @@ def test_config5_twenty_million_triangles(pa, ob):
     assert st["stack_overflows"] == 0
     assert st["extend_rays"] == ost["extend_rays"] and st["shadow_rays"] == ost["shadow_rays"]
     assert np.array_equal(bits(img), bits(osum / np.float32(spp)))
+    # at the configuration's full size (3840x2160, 8 bounces; 3 of its 1024 spp): same bits however the samples are batched or split
+    w, h = 3840, 2160
+    fs, _ = o.camera((0, 25, 70), (0, 18, 0), w, h, use_scene=False, frames=1, samples=1)
+    imgs, counts = [], []
+    for batch, calls in [(3, [3]), (2, [3]), (0, [1, 2])]:
+        wf.set_option(5, batch)
+        wf.allocate(w, h)
+        wf.reset_stats()
+        f = fs.copy()
+        for n in calls:
+            wf.invoke(f, spp=n, max_bounces=8)
+            f["frames"] += n
+            f["samples"] += n
+        imgs.append(wf.read_image())
+        st = wf.stats()
+        counts.append((st["paths"], st["extend_rays"], st["shadow_rays"]))
+        assert st["stack_overflows"] == 0
+    assert counts[0][0] == 3 * w * h and counts[0] == counts[1] == counts[2]
+    assert np.isfinite(imgs[0]).all() and (imgs[0] >= 0).all()
+    assert np.array_equal(bits(imgs[1]), bits(imgs[0])) and np.array_equal(bits(imgs[2]), bits(imgs[0]))
     wf.close()
 
 
