@@ -187,7 +187,10 @@ int pt_build_scene(pt_ctx* ctx, const void* materials, int32_t n_mat, const void
 enum { PT_OPT_NEE = 1, PT_OPT_RNG_MODE = 2, PT_OPT_TRAVERSAL_STATS = 3, PT_OPT_STAGE_TIMING = 4, PT_OPT_SAMPLES_PER_BATCH = 5,
        PT_OPT_TRAVERSE_BLOCKS_PER_CU = 6 /* resident 256-thread blocks per CU of the traversal kernels; 0 = the default (at most 7) */,
        PT_OPT_REFILL_PRIMARY = 7 /* idle lanes (1..64) a traversal wave collects before it fetches new camera rays; default 48 */,
-       PT_OPT_REFILL_BOUNCE = 8 /* the same for bounce and shadow rays; default 40 */ };
+       PT_OPT_REFILL_BOUNCE = 8 /* the same for bounce and shadow rays; default 40 */,
+       PT_OPT_QUANTIZED = 9 /* which node records the traversal kernels walk: 0 the exact 128-byte records, 1 the 64-byte records
+                               with boxes on a 16-bit grid (the exact leaf boxes are then applied at the triangles: hits are the
+                               same), 2 (default) the 64-byte records for trees that exceed the L2 caches */ };
 int pt_set_option(pt_ctx* ctx, int32_t key, int32_t value);
 
 /* ---- multi-GPU tiles, one process per GPU --------------------------------------

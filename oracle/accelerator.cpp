@@ -117,6 +117,7 @@ void Accelerator::AddTriangle(const Triangle& triangle) {
 
 // Accelerator.cs:179-186
 void Accelerator::Clear() {
+    quadRecords = -1;
     references.clear();
     primitives.clear();
     triangles.clear();
@@ -263,13 +264,73 @@ static inline bool RaySpecial(const Ray& ray) {
     return false;
 }
 
+// ---- the quantised walk of the GPU kernels, restated for its counters (no reference counterpart: the reference walks exact boxes;
+// what the reference fixes is which leaves a ray may test — those whose own box passes Box.Intersect — and that is kept: see below).
+// For trees too large for the GPU's L2 caches the kernels walk node records whose child boxes lie on a 16-bit grid over the scene,
+// every plane at least one cell outside the exact box, and evaluate a plane's distance as fma(cell number, cell / d, (grid_min - o) / d).
+// Such a box only steers the walk; when a leaf becomes current its exact box is tested by Box.Intersect's arithmetic together with
+// the walk's distance rule, and only then are its triangles eligible.  Rays that start farther than 16 scene extents from the
+// scene's middle, or with a direction component below 1e-20, take the exact two-wide walk.
+namespace {
+struct QGrid { float mn[3], cell[3], mid[3], reach[3]; };
+QGrid GridOf(const Box& root) {
+    QGrid g;
+    const float rmn[3] = {root.Min.x, root.Min.y, root.Min.z}, rmx[3] = {root.Max.x, root.Max.y, root.Max.z};
+    float ext[3], widest = 0.0f;
+    for (int a = 0; a < 3; a++) { ext[a] = rmx[a] - rmn[a]; widest = ext[a] > widest ? ext[a] : widest; }
+    const bool usable = widest >= 1.0e-10f && widest <= 1.0e15f;
+    for (int a = 0; a < 3; a++) {
+        float eff = ext[a] > widest * 0.015625f ? ext[a] : widest * 0.015625f;
+        if (!(eff >= 1.0e-20f)) eff = 1.0e-20f;
+        g.cell[a] = eff / 65000.0f;
+        g.mn[a] = rmn[a] - 4.0f * g.cell[a];
+        g.mid[a] = 0.5f * rmn[a] + 0.5f * rmx[a];
+        g.reach[a] = usable ? 16.0f * eff : -1.0f;
+    }
+    return g;
+}
+bool RayOffGrid(const QGrid& g, const Ray& ray) {
+    const float d[3] = {ray.Direction.x, ray.Direction.y, ray.Direction.z};
+    const float o[3] = {ray.Origin.x, ray.Origin.y, ray.Origin.z};
+    for (int k = 0; k < 3; k++) {
+        if (!(std::fabs(d[k]) >= 1.0e-20f)) return true;
+        if (!(std::fabs(o[k] - g.mid[k]) <= g.reach[k])) return true;
+    }
+    return false;
+}
+// entry and exit distance of a box through its grid planes
+void GridRange(const QGrid& g, const Box& b, const Ray& ray, float* tmin, float* tmax) {
+    const float mn[3] = {b.Min.x, b.Min.y, b.Min.z}, mx[3] = {b.Max.x, b.Max.y, b.Max.z};
+    const float o[3] = {ray.Origin.x, ray.Origin.y, ray.Origin.z}, inv[3] = {ray.Inverse.x, ray.Inverse.y, ray.Inverse.z};
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; a++) {
+        const double ql = std::floor(((double)mn[a] - (double)g.mn[a]) / (double)g.cell[a]) - 1.0;
+        const double qh = std::ceil(((double)mx[a] - (double)g.mn[a]) / (double)g.cell[a]) + 1.0;
+        const float qa = g.cell[a] * inv[a], qb = (g.mn[a] - o[a]) * inv[a];
+        const float t1 = std::fmaf((float)(uint32_t)ql, qa, qb), t2 = std::fmaf((float)(uint32_t)qh, qa, qb);
+        lo[a] = t1 < t2 ? t1 : t2;
+        hi[a] = t1 < t2 ? t2 : t1;
+    }
+    float m = lo[0] > lo[1] ? lo[0] : lo[1];
+    *tmin = m > lo[2] ? m : lo[2];
+    float x = hi[0] < hi[1] ? hi[0] : hi[1];
+    *tmax = x < hi[2] ? x : hi[2];
+}
+// Box.Intersect plus the walk's distance rule, on "entry distance clamped at +0" as the kernels evaluate it
+bool Admits(float tm, float tx, bool anyHit, float tlimit, float best) {
+    const float tc = tm > 0.0f ? tm : 0.0f;
+    return tc < tx && (anyHit ? tm < tlimit : !(tc > best));
+}
+}  // namespace
+
 // The wide walk: the same tree with every other level skipped.  An interior entry stands for an
 // interior node at an even depth; a step slab-tests its grandchildren (a child that is a leaf
 // stands for itself; slot order: the left child's expansion first), drops the culled ones as in
 // the two-wide walk, makes the nearest survivor current and pushes the others, farthest first.
 // The order key of a child is its entry distance clamped at zero with the two lowest mantissa bits
 // replaced by the slot number; pushed entries carry the key with those bits cleared as distance.
-static bool WalkWide(const Accelerator& acc, const Ray& ray, Intersection& i, bool anyHit, float tlimit, TraversalStats* st) {
+// grid != nullptr: the quantised form (above).
+static bool WalkWide(const Accelerator& acc, const Ray& ray, Intersection& i, bool anyHit, float tlimit, TraversalStats* st, const QGrid* grid = nullptr) {
     const auto& nodes = acc.nodes;
     const auto& triangles = acc.triangles;
     if (st) st->rays++;
@@ -288,7 +349,7 @@ static bool WalkWide(const Accelerator& acc, const Ray& ray, Intersection& i, bo
         }
     };
     std::vector<Entry> stack;
-    Entry cur = nodes[0].Count > 0 ? entryOf(nodes[0]) : Entry{false, 0, 0, 0, 0.0f};   // interior entries name the node itself here
+    Entry cur = nodes[0].Count > 0 ? entryOf(nodes[0]) : Entry{false, 0, 0, 0, 0.0f};   // entries name the node itself here (leaves too: node 0 is the root)
     auto pop = [&]() {
         while (!stack.empty()) {
             Entry e = stack.back();
@@ -299,8 +360,15 @@ static bool WalkWide(const Accelerator& acc, const Ray& ray, Intersection& i, bo
     };
     for (;;) {
         if (cur.leaf) {
+            bool open = true;
+            if (grid) {   // the leaf's own box decides; its triangles are dealt (and counted) either way
+                float tm, tx;
+                BoxIntersect(nodes[cur.node].Bounds, ray, &tm, &tx);
+                open = Admits(tm, tx, anyHit, tlimit, i.Distance);
+            }
             for (int j = cur.first; j < cur.first + cur.count; j++) {
-                testTriangle(j);
+                if (open) testTriangle(j);
+                else if (st) st->tris++;
                 if (occluded) return true;
             }
             if (!pop()) return false;
@@ -318,8 +386,15 @@ static bool WalkWide(const Accelerator& acc, const Ray& ray, Intersection& i, bo
         int nh = 0;
         for (int k = 0; k < nk; k++) {
             float tm;
-            bool h = BoxIntersect(nodes[kids[k]].Bounds, ray, &tm, nullptr);
-            h = h && (anyHit ? tm < tlimit : !(tm > i.Distance));
+            bool h;
+            if (grid) {
+                float tx;
+                GridRange(*grid, nodes[kids[k]].Bounds, ray, &tm, &tx);
+                h = Admits(tm, tx, anyHit, tlimit, i.Distance);
+            } else {
+                h = BoxIntersect(nodes[kids[k]].Bounds, ray, &tm, nullptr);
+                h = h && (anyHit ? tm < tlimit : !(tm > i.Distance));
+            }
             if (!h) continue;
             const float tk = tm > 0.0f ? tm : 0.0f;
             uint32_t bits;
@@ -334,6 +409,7 @@ static bool WalkWide(const Accelerator& acc, const Ray& ray, Intersection& i, bo
         auto entryFor = [&](int slot) {
             const Node& n = nodes[who[slot]];
             Entry e = n.Count > 0 ? entryOf(n) : Entry{false, 0, 0, who[slot], 0.0f};
+            e.node = who[slot];
             const uint32_t bits = keys[slot] & ~3u;
             std::memcpy(&e.tmin, &bits, 4);
             return e;
@@ -344,7 +420,38 @@ static bool WalkWide(const Accelerator& acc, const Ray& ray, Intersection& i, bo
     }
 }
 
+// The GPU library's rule for which records its kernels walk: the quantised ones when the exact 128-byte records (one per interior
+// node at an even depth) exceed the 32 MiB of L2.
+bool Accelerator::WalksQuantized() const {
+    if (quantized == 0) return false;
+    if (quantized == 1) return !nodes.empty();
+    const long long quads = quadRecords >= 0 ? quadRecords : CountQuadRecords();
+    return (unsigned long long)quads * 128ull > (32ull << 20);
+}
+
+// interior nodes at an even depth
+long long Accelerator::CountQuadRecords() const {
+    long long quads = 0;
+    std::vector<std::pair<int, int>> stack;
+    if (!nodes.empty()) stack.push_back({0, 0});
+    while (!stack.empty()) {
+        auto [n, d] = stack.back();
+        stack.pop_back();
+        if (nodes[n].Count > 0) continue;
+        if ((d & 1) == 0) quads++;
+        stack.push_back({nodes[n].LeftFirst, d + 1});
+        stack.push_back({nodes[n].LeftFirst + 1, d + 1});
+    }
+    return quads;
+}
+
 void Accelerator::IntersectCanonical(const Ray& ray, Intersection& i, TraversalStats* st) const {
+    if (WalksQuantized()) {
+        const QGrid g = GridOf(nodes[0].Bounds);
+        if (RaySpecial(ray) || RayOffGrid(g, ray)) Walk(*this, ray, i, false, INF, st);
+        else WalkWide(*this, ray, i, false, INF, st, &g);
+        return;
+    }
     if (RaySpecial(ray)) Walk(*this, ray, i, false, INF, st);
     else WalkWide(*this, ray, i, false, INF, st);
 }
@@ -359,6 +466,11 @@ bool Accelerator::Occluded(const Ray& ray, float tmax, TraversalStats* st) const
     Intersection unused;
     unused.Distance = INF;
     unused.Tri = -1;
+    if (WalksQuantized()) {
+        const QGrid g = GridOf(nodes[0].Bounds);
+        if (RaySpecial(ray) || RayOffGrid(g, ray)) return Walk(*this, ray, unused, true, tmax, st);
+        return WalkWide(*this, ray, unused, true, tmax, st, &g);
+    }
     if (RaySpecial(ray)) return Walk(*this, ray, unused, true, tmax, st);
     return WalkWide(*this, ray, unused, true, tmax, st);
 }
@@ -394,6 +506,7 @@ void Accelerator::Build() {
         int j = primitives[i].Index;
         triangles.push_back(references[j]);
     }
+    quadRecords = CountQuadRecords();
 }
 
 // Accelerator.cs:136-177

@@ -138,6 +138,10 @@ class Scene:
     def build(self):
         _chk(lib().orc_scene_build(self.h))
 
+    def set_quantized(self, mode):
+        """Node records the canonical walks restate: 0 exact, 1 quantised, 2 the GPU library's rule (quantised beyond 32 MiB of records)."""
+        _chk(lib().orc_scene_set_quantized(self.h, int(mode)))
+
     def set_built(self, mats, tris, nodes):
         """Install arrays another builder produced (built order) without building: for trees beyond the literal build's reach."""
         mats, tris, nodes = np.ascontiguousarray(mats, MATERIAL), np.ascontiguousarray(tris, TRIANGLE), np.ascontiguousarray(nodes, NODE)

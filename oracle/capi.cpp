@@ -169,12 +169,21 @@ int orc_scene_set_built(void* h, const void* mats48, int nMat, const void* tris1
     memcpy(a.triangles.data(), tris112, (size_t)nTri * 112);
     a.nodes.resize(nNodes);
     memcpy(a.nodes.data(), nodes32, (size_t)nNodes * 32);
+    a.quadRecords = a.CountQuadRecords();
     s->lights = BuildLightTable(s->scene);
     s->built = true;
     ORC_CATCH
 }
 
 // counts: materials, triangles (post build), nodes, references (pre build), max depth, lights
+// which node records the canonical walks restate: 0 exact, 1 quantised, 2 the GPU library's rule (quantised for trees beyond L2)
+int orc_scene_set_quantized(void* h, int mode) {
+    ORC_TRY
+    if (mode < 0 || mode > 2) throw std::runtime_error("quantized mode must be 0, 1 or 2");
+    ((OrcScene*)h)->scene.accelerator.quantized = mode;
+    ORC_CATCH
+}
+
 int orc_scene_counts(void* h, int32_t* out6) {
     OrcScene* s = (OrcScene*)h;
     out6[0] = (int)s->scene.materials.size();

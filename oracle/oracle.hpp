@@ -126,6 +126,11 @@ public:
     // any hit with 0 < t < tmax (shadow ray)
     bool Occluded(const Ray& ray, float tmax, TraversalStats* st = nullptr) const;
     int MaxDepth() const;
+    // which node records the canonical walks restate: 0 the exact ones, 1 the quantised ones, 2 (default) the GPU library's own rule
+    bool WalksQuantized() const;
+    int quantized = 2;
+    long long CountQuadRecords() const;
+    long long quadRecords = -1;           // set where a tree is installed (Build, orc_scene_set_built) so that walks on many threads only read it
     const std::vector<Triangle>& References() const { return references; }
 
     std::vector<Triangle> triangles;  // Buffer<Triangle> CPU mirror

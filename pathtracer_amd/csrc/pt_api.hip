@@ -74,6 +74,7 @@ struct pt_ctx {
     // scene
     DevScene sc{};
     void *d_pairs = nullptr, *d_quads = nullptr, *d_big = nullptr, *d_hot = nullptr, *d_cold = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+    void *d_qquads = nullptr, *d_gate = nullptr;   // the quantised quad records and the triangles with their leaves' boxes
     bool has_scene = false;
     // image / queues
     int width = 0, height = 0;
@@ -100,7 +101,12 @@ struct pt_ctx {
     // A tree that does not fit L2 (1M small triangles and up) means camera rays that part ways inside it: such scenes gain 3-4 % from
     // waves that fetch camera rays earlier (at 32 idle lanes) and from camera rays queued group by group; scenes whose tree stays in
     // L2 lose 1-4 % with either.  An explicit PT_OPT_REFILL_PRIMARY wins.
-    bool large_tree = false, refill_primary_set = false;
+    bool large_tree = false, refill_primary_set = false, refill_bounce_set = false;
+    // Trees beyond L2 are walked through the 64-byte quantised records (half the bytes per step, the exact leaf boxes applied at the
+    // triangles); trees that stay in L2 are bound by instruction issue and keep the exact 128-byte records.  quant_mode: 0 never,
+    // 1 whenever the records exist, 2 for large trees (PT_OPT_QUANTIZED).
+    bool quant_ok = false;
+    int quant_mode = 2;
     uint64_t local_pixels = 0;
     int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
     void* scratch_dev = nullptr;   // this device's copy of the fixed staging array (pt_trace_closest_noalloc)
@@ -122,9 +128,10 @@ void freeQueues(pt_ctx* c) {
 }
 
 void freeScene(pt_ctx* c) {
-    void** ps[] = {&c->d_pairs, &c->d_quads, &c->d_big, &c->d_hot, &c->d_cold, &c->d_mats, &c->d_lights};
+    void** ps[] = {&c->d_pairs, &c->d_quads, &c->d_big, &c->d_hot, &c->d_cold, &c->d_mats, &c->d_lights, &c->d_qquads, &c->d_gate};
     for (void** p : ps) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
     c->has_scene = false;
+    c->quant_ok = false;
     c->sc = DevScene{};
 }
 
@@ -459,11 +466,16 @@ static int impl_create_single(const pt_config* cfg, pt_ctx** out) {
     }
     c->num_cu = prop.multiProcessorCount;
     int perCu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_extend<false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_extend<false, false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    int perCuQ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuQ, k_extend<false, true>, PT_BLOCK, 0) != hipSuccess || perCuQ < 1) perCuQ = 4;
+    perCu = std::min(perCu, perCuQ);   // one grid size for both forms of the kernel
     c->fit_extend = perCu;
     perCu = std::min(perCu, 7);   // more resident waves than this thrash the caches on incoherent rays
     c->grid_extend = c->num_cu * perCu;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_connect<false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_connect<false, false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuQ, k_connect<false, true>, PT_BLOCK, 0) != hipSuccess || perCuQ < 1) perCuQ = 4;
+    perCu = std::min(perCu, perCuQ);
     c->fit_connect = perCu;
     perCu = std::min(perCu, 7);
     c->grid_connect = c->num_cu * perCu;
@@ -513,7 +525,8 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
             c->grid_connect = c->num_cu * std::min(value ? value : 7, c->fit_connect);
             break;
         case PT_OPT_REFILL_PRIMARY: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_primary = value; c->refill_primary_set = true; break;
-        case PT_OPT_REFILL_BOUNCE: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_bounce = value; break;
+        case PT_OPT_REFILL_BOUNCE: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_bounce = value; c->refill_bounce_set = true; break;
+        case PT_OPT_QUANTIZED: if (value < 0 || value > 2) FAIL(c, PT_E_INVALID_ARG, "quantized %d", value); c->quant_mode = value; break;
         case PT_OPT_SAMPLES_PER_BATCH: if (value < 0) FAIL(c, PT_E_INVALID_ARG, "samples_per_batch %d", value); c->cfg.samples_per_batch = value; break;
         default: FAIL(c, PT_E_INVALID_ARG, "unknown option %d", key);
     }
@@ -595,11 +608,42 @@ int pt_reset_accumulation(pt_ctx* c) {
 }
 
 // The wide pass over the queue, then the two-wide pass over the rays it set aside (normally none).
+// whether the traversal kernels walk the quantised records of the installed scene
+static bool useQuant(const pt_ctx* c) { return c->quant_ok && (c->quant_mode == 1 || (c->quant_mode == 2 && c->large_tree)); }
+
+// Idle lanes a wave collects before it fetches bounce or shadow rays.  Over the quantised records a step costs the memory pipeline
+// four loads instead of seven, and waves that refill at 24 idle lanes (16 to 32 measure alike) are 5 % faster than at 40.
+static uint32_t bounceRefill(const pt_ctx* c) { return (uint32_t)((useQuant(c) && !c->refill_bounce_set) ? 24 : c->refill_bounce); }
+
 static void launchExtend(pt_ctx* c, bool stats, int cur, uint32_t refillMin) {
-    if (stats) {
-        hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
+    const dim3 grid(c->grid_extend), block(PT_BLOCK);
+    if (useQuant(c)) {
+        if (stats) hipLaunchKernelGGL((k_extend<true, true>), grid, block, 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
+        else hipLaunchKernelGGL((k_extend<false, true>), grid, block, 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
     } else {
-        hipLaunchKernelGGL(k_extend<false>, dim3(c->grid_extend), dim3(PT_BLOCK), 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
+        if (stats) hipLaunchKernelGGL((k_extend<true, false>), grid, block, 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
+        else hipLaunchKernelGGL((k_extend<false, false>), grid, block, 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
+    }
+}
+static void launchConnect(pt_ctx* c, bool stats, int cur, hipStream_t on) {
+    const dim3 grid(c->grid_connect), block(PT_BLOCK);
+    const uint32_t refillMin = bounceRefill(c);
+    if (useQuant(c)) {
+        if (stats) hipLaunchKernelGGL((k_connect<true, true>), grid, block, 0, on, c->sc, c->q, c->d_ctl, cur, refillMin);
+        else hipLaunchKernelGGL((k_connect<false, true>), grid, block, 0, on, c->sc, c->q, c->d_ctl, cur, refillMin);
+    } else {
+        if (stats) hipLaunchKernelGGL((k_connect<true, false>), grid, block, 0, on, c->sc, c->q, c->d_ctl, cur, refillMin);
+        else hipLaunchKernelGGL((k_connect<false, false>), grid, block, 0, on, c->sc, c->q, c->d_ctl, cur, refillMin);
+    }
+}
+static void launchTrace(pt_ctx* c, bool anyhit, const TraceSource& src, int n) {
+    const dim3 grid(launchGrid((uint32_t)n)), block(PT_BLOCK);
+    if (useQuant(c)) {
+        if (anyhit) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, c->stream, c->sc, src, n, c->d_ctl);
+        else hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, c->stream, c->sc, src, n, c->d_ctl);
+    } else {
+        if (anyhit) hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, c->stream, c->sc, src, n, c->d_ctl);
+        else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, c->stream, c->sc, src, n, c->d_ctl);
     }
 }
 
@@ -660,7 +704,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             rp.last_bounce = (b == max_bounces - 1) ? 1 : 0;
             {
                 StageTimer t(c, b == 0 ? 4 : 1);
-                launchExtend(c, stats, cur, (uint32_t)(b == 0 ? ((c->large_tree && !c->refill_primary_set) ? 32 : c->refill_primary) : c->refill_bounce));
+                launchExtend(c, stats, cur, (uint32_t)(b == 0 ? ((c->large_tree && !c->refill_primary_set) ? 32 : c->refill_primary) : bounceRefill(c)));
                 c->host_stats.extend_launches++;
             }
             if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_connected, 0)); connectPending = false; }
@@ -677,11 +721,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
                     HIPCHECK(c, hipStreamWaitEvent(c->stream_connect, c->ev_shaded, 0));
                     on = c->stream_connect;
                 }
-                if (stats) {
-                    hipLaunchKernelGGL(k_connect<true>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, on, c->sc, c->q, c->d_ctl, cur, (uint32_t)c->refill_bounce);
-                } else {
-                    hipLaunchKernelGGL(k_connect<false>, dim3(c->grid_connect), dim3(PT_BLOCK), 0, on, c->sc, c->q, c->d_ctl, cur, (uint32_t)c->refill_bounce);
-                }
+                launchConnect(c, stats, cur, on);
                 if (beside) { HIPCHECK(c, hipEventRecord(c->ev_connected, c->stream_connect)); connectPending = true; }
                 c->host_stats.connect_launches++;
             }
@@ -839,7 +879,7 @@ static int traceCommon(pt_ctx* c, bool anyhit, const float* o_d, const float* tm
         TRY(hipMalloc((void**)&d_occ, (size_t)n));
         TRY(hipMemcpyAsync(d_tmax, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
         TraceSource src{d_rays, d_tmax, nullptr, nullptr, nullptr, d_occ};
-        hipLaunchKernelGGL(k_trace<true>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl);
+        launchTrace(c, true, src, n);
         TRY(hipGetLastError());
         TRY(hipMemcpyAsync(occ, d_occ, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     } else {
@@ -847,7 +887,7 @@ static int traceCommon(pt_ctx* c, bool anyhit, const float* o_d, const float* tm
         TRY(hipMalloc((void**)&d_t, (size_t)n * 4));
         if (uv) TRY(hipMalloc((void**)&d_uv, (size_t)n * 8));
         TraceSource src{d_rays, nullptr, d_tri, d_t, d_uv, nullptr};
-        hipLaunchKernelGGL(k_trace<false>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl);
+        launchTrace(c, false, src, n);
         TRY(hipGetLastError());
         if (tri) TRY(hipMemcpyAsync(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         if (t) TRY(hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -893,7 +933,7 @@ int pt_trace_closest_noalloc(pt_ctx* c, const float* o_d, int32_t n, int32_t* tr
     HIPCHECK(c, hipMemcpyAsync(d_rays, o_d, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, 0ull);
     TraceSource src{d_rays, nullptr, d_tri, d_t, uv ? d_uv : nullptr, nullptr};
-    hipLaunchKernelGGL(k_trace<false>, dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), 0, c->stream, c->sc, src, n, c->d_ctl);
+    launchTrace(c, false, src, n);
     HIPCHECK(c, hipGetLastError());
     if (tri) HIPCHECK(c, hipMemcpyAsync(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (t) HIPCHECK(c, hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -964,7 +1004,7 @@ static int impl_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t ite
     for (int it = 0; it < iters + 1; it++) {   // the first launch warms caches and is not counted
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, (uint32_t)n, 0ull);
         HIPCHECK(c, hipEventRecord(a, c->stream));
-        launchExtend(c, stats, 0, (uint32_t)c->refill_bounce);
+        launchExtend(c, stats, 0, bounceRefill(c));
         HIPCHECK(c, hipEventRecord(b, c->stream));
         HIPCHECK(c, hipStreamSynchronize(c->stream));
         float ms = 0.0f;
@@ -1043,8 +1083,13 @@ struct SceneWork {
     void* tmp = nullptr;
     size_t tmpBytes = 0;
     void *pairs = nullptr, *quads = nullptr, *big = nullptr, *hot = nullptr, *cold = nullptr, *mats = nullptr, *lights = nullptr;   // the new scene
+    void *qquads = nullptr, *gate = nullptr;
+    uint32_t* d_qbad = nullptr;
+    uint32_t qbad = 0;         // a box that does not fit the grid (non-finite): the scene keeps to the exact records
     hipEvent_t ea = nullptr, eb = nullptr;
     float lightSum = 0.0f;     // written by copies queued on the stream
+    uint32_t rbTri[3] = {0, 0, 0}, rbNode[4] = {0, 0, 0, 0};   // small read-backs that size allocations: kept here, not on a caller's stack,
+                                                              // because a copy may still be pending when an error return unwinds
     ptbuild::BNode root{};
     uint32_t nLights = 0, nQuads = 0;
     explicit SceneWork(pt_ctx* ctx) : c(ctx) {}
@@ -1053,7 +1098,7 @@ struct SceneWork {
     ~SceneWork() {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         void* all[] = {d_in, d_sorted, d_nodes, bn, d_flagA, d_idxA, d_flagB, d_idxB, d_bad, d_parent, d_refs, d_anc[0], d_anc[1], d_dep[0], d_dep[1], d_check, tmp,
-                       pairs, quads, big, hot, cold, mats, lights};
+                       pairs, quads, big, hot, cold, mats, lights, qquads, gate, d_qbad};
         for (void* p : all) if (p) (void)hipFree(p);
         if (ea) c->pool.push_back(ea);
         if (eb) c->pool.push_back(eb);
@@ -1083,13 +1128,12 @@ static int repackOnDevice(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn, cons
         hipLaunchKernelGGL(ptrepack::k_triangles, dim3(launchGrid(n)), dim3(256), 0, c->stream, w.d_sorted, n, (const float4*)w.mats, n_mat,
                            (float4*)w.hot, (float4*)w.cold, w.d_flagA, w.d_bad);
         TRY(ptrepack::exclusiveScan(c->stream, w.d_flagA, w.d_idxA, n, &w.tmp, &w.tmpBytes));
-        uint32_t lastFlag = 0, lastIdx = 0, bad = 0;
-        TRY(hipMemcpyAsync(&lastFlag, w.d_flagA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&lastIdx, w.d_idxA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        TRY(hipMemcpyAsync(&bad, w.d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&w.rbTri[0], w.d_flagA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&w.rbTri[1], w.d_idxA + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&w.rbTri[2], w.d_bad, 4, hipMemcpyDeviceToHost, c->stream));
         TRY(hipStreamSynchronize(c->stream));
-        if (bad) FAIL(c, PT_E_INVALID_ARG, "a triangle has a material index outside [0, %d)", n_mat);
-        w.nLights = lastFlag + lastIdx;
+        if (w.rbTri[2]) FAIL(c, PT_E_INVALID_ARG, "a triangle has a material index outside [0, %d)", n_mat);
+        w.nLights = w.rbTri[0] + w.rbTri[1];
         if (w.nLights) {
             // rows in triangle order; the running sum rounds as a CPU loop over the triangles would (d_bad is free again: it receives the total)
             TRY(hipMalloc(&w.lights, (size_t)w.nLights * 3 * sizeof(float4)));
@@ -1103,7 +1147,7 @@ static int repackOnDevice(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn, cons
     hipLaunchKernelGGL(ptrepack::k_flags, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_flagA, w.d_flagB);
     TRY(ptrepack::exclusiveScan(c->stream, w.d_flagA, w.d_idxA, nn, &w.tmp, &w.tmpBytes));
     TRY(ptrepack::exclusiveScan(c->stream, w.d_flagB, w.d_idxB, nn, &w.tmp, &w.tmpBytes));
-    uint32_t v[4] = {0, 0, 0, 0};
+    uint32_t* const v = w.rbNode;
     TRY(hipMemcpyAsync(&v[0], w.d_flagA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
     TRY(hipMemcpyAsync(&v[1], w.d_idxA + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
     TRY(hipMemcpyAsync(&v[2], w.d_flagB + (nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
@@ -1117,6 +1161,18 @@ static int repackOnDevice(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn, cons
     if (nBig) TRY(hipMalloc(&w.big, (size_t)nBig * 8));
     hipLaunchKernelGGL(ptrepack::k_records, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_idxA, w.d_idxB, w.d_flagB, (float4*)w.pairs,
                        (float4*)w.quads, (uint2*)w.big);
+    // the same records in 64 bytes on the scene's grid, and the triangles with their leaves' boxes beside them
+    TRY(hipMalloc((void**)&w.d_qbad, 4));
+    TRY(hipMemsetAsync(w.d_qbad, 0, 4, c->stream));
+    if (nQuads) {
+        TRY(hipMalloc(&w.qquads, (size_t)nQuads * 64));
+        hipLaunchKernelGGL(ptrepack::k_qrecords, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_idxA, w.d_idxB, (uint4*)w.qquads, w.d_qbad);
+    }
+    if (n) {
+        TRY(hipMalloc(&w.gate, (size_t)n * 64));
+        hipLaunchKernelGGL(ptrepack::k_tri_gate, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, (const float4*)w.hot, (float4*)w.gate);
+    }
+    TRY(hipMemcpyAsync(&w.qbad, w.d_qbad, 4, hipMemcpyDeviceToHost, c->stream));
     TRY(hipMemcpyAsync(&w.root, w.bn, sizeof(w.root), hipMemcpyDeviceToHost, c->stream));
     return PT_OK;
 }
@@ -1125,7 +1181,8 @@ static int repackOnDevice(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn, cons
 static void adoptScene(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn) {
     freeScene(c);
     c->d_pairs = w.pairs; c->d_quads = w.quads; c->d_big = w.big; c->d_hot = w.hot; c->d_cold = w.cold; c->d_mats = w.mats; c->d_lights = w.lights;
-    w.pairs = w.quads = w.big = w.hot = w.cold = w.mats = w.lights = nullptr;
+    c->d_qquads = w.qquads; c->d_gate = w.gate;
+    w.pairs = w.quads = w.big = w.hot = w.cold = w.mats = w.lights = w.qquads = w.gate = nullptr;
     DevScene& sc = c->sc;
     sc.pairs = (const float4*)c->d_pairs;
     sc.quads = (const float4*)c->d_quads;
@@ -1134,6 +1191,8 @@ static void adoptScene(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn) {
     sc.tri_cold = (const float4*)c->d_cold;
     sc.mats = (const float4*)c->d_mats;
     sc.lights = (const float4*)c->d_lights;
+    sc.qquads = (const uint4*)c->d_qquads;
+    sc.tri_gate = (const float4*)c->d_gate;
     sc.n_nodes = n ? (int32_t)nn : 0;
     sc.n_tris = (int32_t)n;
     sc.n_lights = (int32_t)w.nLights;
@@ -1142,6 +1201,10 @@ static void adoptScene(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn) {
     for (int k = 0; k < 3; k++) { sc.root_min[k] = w.root.mn[k]; sc.root_max[k] = w.root.mx[k]; }
     sc.root_left = w.root.left >= 0 ? w.root.left : w.root.first;
     sc.root_count = w.root.left >= 0 ? 0 : w.root.count;
+    ptrepack::QGrid grid;
+    ptrepack::gridOf(w.root.mn, w.root.mx, &grid);   // the expression k_qrecords evaluated on the device
+    for (int k = 0; k < 3; k++) { sc.grid_min[k] = grid.mn[k]; sc.grid_cell[k] = grid.cell[k]; sc.grid_mid[k] = grid.mid[k]; sc.grid_reach[k] = grid.reach[k]; }
+    c->quant_ok = n > 0 && w.qbad == 0 && (w.nQuads == 0 || c->d_qquads != nullptr) && c->d_gate != nullptr;
     c->has_scene = true;
 }
 

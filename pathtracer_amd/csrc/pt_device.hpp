@@ -63,6 +63,15 @@ __device__ __forceinline__ f4 operator+(f4 a, f4 b) { return mk4(a.x + b.x, a.y 
 // tri_cold: 48 B per triangle: the three vertex normals, read once per shaded hit.
 // mats:     the host's Material[] verbatim (48 B = 3 x float4).
 // lights:   48 B per emissive triangle: (V1, running area sum) (V2, material bits) (V3, 0).
+// qquads:   the quad records again in 64 bytes, for trees that do not fit the L2 caches: the same four entries, but the
+//           boxes as 16-bit cell numbers of one grid over the scene (cell = extent / 65000 per axis), every plane moved
+//           outward by at least one whole cell.  Three uint4 of planes — (lo_x, lo_y) (lo_z, hi_x) (hi_y, hi_z), each
+//           plane two dwords = children (0 | 1 << 16), (2 | 3 << 16) — then the entries.  Such a box only decides where the
+//           walk goes; whether a leaf's triangles are eligible is decided by the leaf's exact box, which travels with each
+//           of its triangles in tri_gate (below).  Empty slots hold cell 0 on every plane: a point box, which no ray passes
+//           (entry and exit distance coincide on every axis).
+// tri_gate: 64 B per triangle: (V1.xyz, material bits) (V2-V1, box.min.x) (V3-V1, box.min.y) (box.min.z, box.max.xyz),
+//           the box being that of the triangle's leaf, verbatim from the host's Node.
 struct DevScene {
     const float4* pairs;
     const float4* quads;
@@ -71,10 +80,15 @@ struct DevScene {
     const float4* tri_cold;
     const float4* mats;
     const float4* lights;
+    const uint4* qquads;
+    const float4* tri_gate;
     int32_t n_nodes, n_tris, n_lights;
     float light_total;
     float root_min[3], root_max[3];
     int32_t root_left, root_count;
+    // the grid of qquads: plane = grid_min + cell number * grid_cell; rays that start farther than grid_reach from
+    // grid_mid on some axis do not take the quantised walk (see rayOffGrid)
+    float grid_min[3], grid_cell[3], grid_mid[3], grid_reach[3];
 };
 
 // Counters and queue sizes shared by the stages of one context (device memory).
@@ -233,6 +247,19 @@ __device__ __forceinline__ bool raySpecial(f3 o, f3 d) {
     return !(dOk && oOk);
 }
 
+// The quantised walk (traverseWave<..., QUANT = true>) evaluates a grid plane's distance as fma(cell number, A, B) with
+// A = cell * (1/d) and B = (grid_min - o) * (1/d), both rounded once per ray.  Against the reference's (plane - o) * (1/d)
+// on the exact plane that differs by at most 6 * 2^-24 * R in units of position, R being the largest distance on that
+// axis between the origin and the scene's box; the records keep every plane at least one cell = extent / 65000 away
+// from anything inside, which covers that error while R <= 42 extents.  Rays that start farther out than 16 extents
+// (grid_reach) or whose direction has a component below 1e-20 (A or B could overflow) take the exact two-wide walk.
+__device__ __forceinline__ bool rayOffGrid(const DevScene& sc, f3 o, f3 d) {
+    const bool dOk = fabsf(d.x) >= 1.0e-20f && fabsf(d.y) >= 1.0e-20f && fabsf(d.z) >= 1.0e-20f;
+    const bool oOk = fabsf(o.x - sc.grid_mid[0]) <= sc.grid_reach[0] && fabsf(o.y - sc.grid_mid[1]) <= sc.grid_reach[1] &&
+                     fabsf(o.z - sc.grid_mid[2]) <= sc.grid_reach[2];
+    return !(dOk && oOk);
+}
+
 // ------------------------------------------------------------------ traversal
 struct HitRec { float t; int32_t tri; float u, v; };
 
@@ -371,7 +398,7 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 #define PT_MARK(name)
 #endif
 
-template <bool ANYHIT, bool STATS, class Source>
+template <bool ANYHIT, bool STATS, bool QUANT, class Source>
 __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, unsigned long long* leafq, const Source& src,
                                              uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched, uint32_t refillMin,
                                              unsigned long long* specialRays) {
@@ -392,6 +419,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
 
     uint32_t rayIdx = PT_NO_RAY;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0);
+    f3 qa = mk3(0, 0, 0), qb = mk3(0, 0, 0);   // QUANT: distance of grid plane number q on an axis = fma(q, qa, qb)
     float best = PT_INF, bu = 0.0f, bv = 0.0f, tlimit = PT_INF;
     int32_t bestTri = -1;
     bool occluded = false, special = false;
@@ -478,6 +506,11 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     occluded = false;
                     sp = 0;
                     special = raySpecial(o, d);
+                    if (QUANT) {
+                        special = special || rayOffGrid(sc, o, d);
+                        qa = mk3(sc.grid_cell[0] * inv.x, sc.grid_cell[1] * inv.y, sc.grid_cell[2] * inv.z);
+                        qb = mk3((sc.grid_min[0] - o.x) * inv.x, (sc.grid_min[1] - o.y) * inv.y, (sc.grid_min[2] - o.z) * inv.z);
+                    }
                     float tr;
                     // the root test is done once per ray: always the NaN-propagating form
                     const bool in = sc.n_nodes > 0 &&
@@ -519,54 +552,56 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             {
                 if ((int32_t)cur > 0 && !special) {
                     if (STATS) (*nsteps)++;
-                    const float4* p = sc.quads + 8 * (size_t)(cur - 1u);
-                    const float4 mnx = p[0], mny = p[1], mnz = p[2], mxx = p[3], mxy = p[4], mxz = p[5];
-                    const float4 eb = p[6];
                     uint32_t k0, k1, k2, k3;
-                    uint32_t e0 = __float_as_uint(eb.x), e1 = __float_as_uint(eb.y), e2 = __float_as_uint(eb.z), e3 = __float_as_uint(eb.w);
-#ifdef PT_PACKED_SLAB
-                    // slab distances of two children per packed instruction: (plane - o) * inv, Box.cs:51-79
-                    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-                    const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-#define PT_PLANES(LO, HI, A, B)                                                          \
-                    const v2f LO##x = (v2f{mnx.A, mnx.B} - ox) * ix, HI##x = (v2f{mxx.A, mxx.B} - ox) * ix; \
-                    const v2f LO##y = (v2f{mny.A, mny.B} - oy) * iy, HI##y = (v2f{mxy.A, mxy.B} - oy) * iy; \
-                    const v2f LO##z = (v2f{mnz.A, mnz.B} - oz) * iz, HI##z = (v2f{mxz.A, mxz.B} - oz) * iz;
-                    PT_PLANES(a01, b01, x, y)
-                    PT_PLANES(a23, b23, z, w)
-#undef PT_PLANES
-#define PT_QUAD_CHILD(K, E, LO, HI, H, SLOT)                                                                               \
-                    {                                                                                                       \
-                        const float tm = fmaxf(fmaxf(fminf(LO##x.H, HI##x.H), fminf(LO##y.H, HI##y.H)), fminf(LO##z.H, HI##z.H)); \
-                        const float tx = fminf(fminf(fmaxf(LO##x.H, HI##x.H), fmaxf(LO##y.H, HI##y.H)), fmaxf(LO##z.H, HI##z.H)); \
-                        const bool h = tx > 0.0f && tm < tx && (ANYHIT ? tm < tlimit : !(tm > best));                       \
-                        const int32_t tb = __float_as_int(tm);                                                              \
-                        K = h ? (((uint32_t)(tb > 0 ? tb : 0) & ~3u) | SLOT) : PT_KEY_MISS;                                 \
+                    uint32_t e0, e1, e2, e3;
+                    // Order key of a child from its entry and exit distances.  Box.cs:51-79 passes when tx > 0 and tm < tx; with
+                    // t0 = max(tm, +0) that is t0 < tx (t0 >= 0 makes tx positive, tm <= t0; negative distances and -0 clamp to +0).
+                    // The best distance is positive, so "not beyond the best hit" reads the same on t0 as on tm.
+#define PT_QUAD_KEY(K, TM, TX, SLOT)                                                                          \
+                    {                                                                                          \
+                        const int32_t tb = __float_as_int(TM);                                                 \
+                        const int32_t t0 = tb > 0 ? tb : 0;                                                    \
+                        const float tc = __int_as_float(t0);                                                   \
+                        const bool h = tc < (TX) && (ANYHIT ? (TM) < tlimit : !(tc > best));                   \
+                        K = h ? (((uint32_t)t0 & ~3u) | SLOT) : PT_KEY_MISS;                                   \
                     }
-                    PT_QUAD_CHILD(k0, e0, a01, b01, x, 0u)
-                    PT_QUAD_CHILD(k1, e1, a01, b01, y, 1u)
-                    PT_QUAD_CHILD(k2, e2, a23, b23, x, 2u)
-                    PT_QUAD_CHILD(k3, e3, a23, b23, y, 3u)
-#else
-#define PT_QUAD_CHILD(K, E, C, SLOT)                                                                          \
+                    if (QUANT) {
+                        const uint4* p = sc.qquads + 4 * (size_t)(cur - 1u);
+                        const uint4 w0 = p[0], w1 = p[1], w2 = p[2], we = p[3];
+                        e0 = we.x; e1 = we.y; e2 = we.z; e3 = we.w;
+                        // distances of the six grid planes of a child: fma(cell number, cell / d, (grid_min - o) / d), see rayOffGrid
+#define PT_QUANT_CHILD(K, LX, LY, LZ, HX, HY, HZ, SLOT)                                                       \
+                    {                                                                                          \
+                        const float t1 = fmaf((float)(LX), qa.x, qb.x), t2 = fmaf((float)(HX), qa.x, qb.x);    \
+                        const float t3 = fmaf((float)(LY), qa.y, qb.y), t4 = fmaf((float)(HY), qa.y, qb.y);    \
+                        const float t5 = fmaf((float)(LZ), qa.z, qb.z), t6 = fmaf((float)(HZ), qa.z, qb.z);    \
+                        const float tm = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));            \
+                        const float tx = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));            \
+                        PT_QUAD_KEY(K, tm, tx, SLOT)                                                           \
+                    }
+                        PT_QUANT_CHILD(k0, w0.x & 0xffffu, w0.z & 0xffffu, w1.x & 0xffffu, w1.z & 0xffffu, w2.x & 0xffffu, w2.z & 0xffffu, 0u)
+                        PT_QUANT_CHILD(k1, w0.x >> 16, w0.z >> 16, w1.x >> 16, w1.z >> 16, w2.x >> 16, w2.z >> 16, 1u)
+                        PT_QUANT_CHILD(k2, w0.y & 0xffffu, w0.w & 0xffffu, w1.y & 0xffffu, w1.w & 0xffffu, w2.y & 0xffffu, w2.w & 0xffffu, 2u)
+                        PT_QUANT_CHILD(k3, w0.y >> 16, w0.w >> 16, w1.y >> 16, w1.w >> 16, w2.y >> 16, w2.w >> 16, 3u)
+#undef PT_QUANT_CHILD
+                    } else {
+                        const float4* p = sc.quads + 8 * (size_t)(cur - 1u);
+                        const float4 mnx = p[0], mny = p[1], mnz = p[2], mxx = p[3], mxy = p[4], mxz = p[5];
+                        const float4 eb = p[6];
+                        e0 = __float_as_uint(eb.x); e1 = __float_as_uint(eb.y); e2 = __float_as_uint(eb.z); e3 = __float_as_uint(eb.w);
+#define PT_QUAD_CHILD(K, C, SLOT)                                                                             \
                     {                                                                                          \
                         float tm, tx;                                                                          \
                         slabRange(mnx.C, mny.C, mnz.C, mxx.C, mxy.C, mxz.C, o, inv, &tm, &tx);                 \
-                        const int32_t tb = __float_as_int(tm);   /* negative distances (and -0) clamp to +0 */ \
-                        const int32_t t0 = tb > 0 ? tb : 0;                                                    \
-                        /* Box.cs:51-79 passes when tx > 0 and tm < tx; with t0 = max(tm, +0) that is t0 < tx  \
-                           (t0 >= 0 makes tx positive, tm <= t0).  The best distance is positive, so           \
-                           "not beyond the best hit" reads the same on t0 as on tm. */                          \
-                        const float tc = __int_as_float(t0);                                                   \
-                        const bool h = tc < tx && (ANYHIT ? tm < tlimit : !(tc > best));                       \
-                        K = h ? (((uint32_t)t0 & ~3u) | SLOT) : PT_KEY_MISS;                                   \
+                        PT_QUAD_KEY(K, tm, tx, SLOT)                                                           \
                     }
-                    PT_QUAD_CHILD(k0, e0, x, 0u)
-                    PT_QUAD_CHILD(k1, e1, y, 1u)
-                    PT_QUAD_CHILD(k2, e2, z, 2u)
-                    PT_QUAD_CHILD(k3, e3, w, 3u)
-#endif
+                        PT_QUAD_CHILD(k0, x, 0u)
+                        PT_QUAD_CHILD(k1, y, 1u)
+                        PT_QUAD_CHILD(k2, z, 2u)
+                        PT_QUAD_CHILD(k3, w, 3u)
 #undef PT_QUAD_CHILD
+                    }
+#undef PT_QUAD_KEY
 #define PT_CSWAP(KA, EA, KB, EB)                                                  \
                     {                                                              \
                         const bool sw = KB < KA;                                   \
@@ -672,7 +707,25 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     sched[4]++;
                 }
             }
-            if (busy) {
+            if (QUANT) {
+                // the walk came here through widened boxes: the leaf's own box (Node.Bounds, verbatim) decides whether its
+                // triangles are eligible, by the reference's slab test and the walk's distance rule.  Owners on the exact
+                // two-wide walk have applied both already.
+                const f3 pinv = mk3(__shfl(inv.x, (int)own), __shfl(inv.y, (int)own), __shfl(inv.z, (int)own));
+                const float bestO = __shfl(best, (int)own);
+                const bool exactO = __shfl((int)special, (int)own) != 0;
+                if (busy) {
+                    const float4* tp = sc.tri_gate + 4 * (size_t)j;
+                    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+                    float tm, tx;
+                    slabRange(q1.w, q2.w, q3.x, q3.y, q3.z, q3.w, po, pinv, &tm, &tx);
+                    const int32_t tb = __float_as_int(tm);
+                    const float tc = __int_as_float(tb > 0 ? tb : 0);
+                    const bool open = exactO || (tc < tx && (ANYHIT ? tm < limO : !(tc > bestO)));
+                    hit = open && triangleTest(q0, q1, q2, po, pd, &tt, &tu, &tv);
+                    if (ANYHIT) hit = hit && tt < limO;
+                }
+            } else if (busy) {
                 const float4* tp = sc.tri_hot + 3 * (size_t)j;
                 const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
                 hit = triangleTest(q0, q1, q2, po, pd, &tt, &tu, &tv);

@@ -120,7 +120,7 @@ struct ExtendSource {
     }
 };
 
-template <bool STATS>
+template <bool STATS, bool QUANT>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene
     src.d = q.d[cur];
     src.hit = q.hit;
     uint32_t sched[5] = {0, 0, 0, 0, 0};
-    traverseWave<false, STATS>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
+    traverseWave<false, STATS, QUANT>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
     if (STATS) {
         waveAdd64(&ctl->extend_steps, steps);
         waveAdd64(&ctl->extend_tris, tris);
@@ -176,7 +176,7 @@ struct ConnectSource {
     }
 };
 
-template <bool STATS>
+template <bool STATS, bool QUANT>
 __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScen
     src.sc = q.sc;
     src.plane = q.plane;
     uint32_t sched[5] = {0, 0, 0, 0, 0};
-    traverseWave<true, STATS>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
+    traverseWave<true, STATS, QUANT>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
     if (STATS) {
         waveAdd64(&ctl->shadow_steps, steps);
         waveAdd64(&ctl->shadow_tris, tris);
@@ -545,7 +545,7 @@ struct TraceSource {
 };
 
 // One wave per 64 rays (grid sized by the caller), no shared cursor.
-template <bool ANYHIT>
+template <bool ANYHIT, bool QUANT>
 __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src, int n, Ctl* ctl) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
@@ -554,7 +554,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src
     uint32_t steps = 0, tris = 0, overflow = 0;
     uint32_t sched[5] = {0, 0, 0, 0, 0};
     // every wave traces its own 64 rays and never refills: the threshold is not used
-    traverseWave<ANYHIT, false>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, 64u, &ctl->special_rays);
+    traverseWave<ANYHIT, false, QUANT>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, 64u, &ctl->special_rays);
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
 }
 

@@ -121,6 +121,76 @@ __global__ void __launch_bounds__(256) k_records(const BNode* nodes, uint32_t n_
     }
 }
 
+// ---- quantised quad records and gated triangles (see pt_device.hpp: DevScene.qquads / tri_gate, rayOffGrid)
+// The grid: per axis 65000 cells over the root box (an axis much thinner than the widest one gets cells of the widest
+// axis / 64, so that no cell is degenerate), four spare cells below.  grid_reach = -1 switches the quantised walk off for
+// every ray when the scene is too small or too large for the error bound's assumptions (no overflow or underflow in
+// cell / d and (grid_min - o) / d).
+struct QGrid { float mn[3], cell[3], mid[3], reach[3]; };
+__host__ __device__ inline void gridOf(const float* rmn, const float* rmx, QGrid* g) {
+    float ext[3], widest = 0.0f;
+    for (int a = 0; a < 3; a++) { ext[a] = rmx[a] - rmn[a]; widest = ext[a] > widest ? ext[a] : widest; }
+    const bool usable = widest >= 1.0e-10f && widest <= 1.0e15f;
+    for (int a = 0; a < 3; a++) {
+        float eff = ext[a] > widest * 0.015625f ? ext[a] : widest * 0.015625f;
+        if (!(eff >= 1.0e-20f)) eff = 1.0e-20f;
+        g->cell[a] = eff / 65000.0f;
+        g->mn[a] = rmn[a] - 4.0f * g->cell[a];
+        g->mid[a] = 0.5f * rmn[a] + 0.5f * rmx[a];
+        g->reach[a] = usable ? 16.0f * eff : -1.0f;
+    }
+}
+// One 64-byte record per quad record: cell numbers in double arithmetic, one whole cell outward of the cell that holds the plane.
+__global__ void __launch_bounds__(256) k_qrecords(const BNode* nodes, uint32_t n_nodes, const uint32_t* quad_idx, const uint32_t* big_idx, uint4* qquads, uint32_t* bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const BNode& nd = nodes[i];
+    if (!(nd.left >= 0 && (nd.level & 1u) == 0u)) return;
+    QGrid g;
+    gridOf(nodes[0].mn, nodes[0].mx, &g);
+    int32_t kids[4];
+    int nk = 0;
+    for (int32_t ch = nd.left; ch <= nd.left + 1; ch++) {
+        if (nodes[ch].left < 0) kids[nk++] = ch;
+        else { kids[nk++] = nodes[ch].left; kids[nk++] = nodes[ch].left + 1; }
+    }
+    uint32_t lo[3][4] = {}, hi[3][4] = {}, ent[4] = {0, 0, 0, 0};
+    for (int k = 0; k < nk; k++) {
+        const BNode& kd = nodes[kids[k]];
+        for (int a = 0; a < 3; a++) {
+            const double vl = ((double)kd.mn[a] - (double)g.mn[a]) / (double)g.cell[a];
+            const double vh = ((double)kd.mx[a] - (double)g.mn[a]) / (double)g.cell[a];
+            double ql = floor(vl) - 1.0, qh = ceil(vh) + 1.0;
+            if (!(ql >= 0.0) || !(qh <= 65535.0)) { atomicOr(bad, 1u); ql = 0.0; qh = 65535.0; }   // also catches NaN
+            lo[a][k] = (uint32_t)ql;
+            hi[a][k] = (uint32_t)qh;
+        }
+        ent[k] = kd.left >= 0 ? quad_idx[kids[k]] + 1u : leafEntry(kd, big_idx[kids[k]]);
+    }
+#define PT_PK(v, a, b) ((v)[a] | ((v)[b] << 16))
+    uint4* q = qquads + 4 * (size_t)quad_idx[i];
+    q[0] = make_uint4(PT_PK(lo[0], 0, 1), PT_PK(lo[0], 2, 3), PT_PK(lo[1], 0, 1), PT_PK(lo[1], 2, 3));
+    q[1] = make_uint4(PT_PK(lo[2], 0, 1), PT_PK(lo[2], 2, 3), PT_PK(hi[0], 0, 1), PT_PK(hi[0], 2, 3));
+    q[2] = make_uint4(PT_PK(hi[1], 0, 1), PT_PK(hi[1], 2, 3), PT_PK(hi[2], 0, 1), PT_PK(hi[2], 2, 3));
+    q[3] = make_uint4(ent[0], ent[1], ent[2], ent[3]);
+#undef PT_PK
+}
+// The triangles of every leaf with that leaf's box beside them.
+__global__ void __launch_bounds__(256) k_tri_gate(const BNode* nodes, uint32_t n_nodes, const float4* hot, float4* gate) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const BNode& nd = nodes[i];
+    if (nd.left >= 0) return;
+    for (int32_t j = nd.first; j < nd.first + nd.count; j++) {
+        const float4 a = hot[3 * (size_t)j], b = hot[3 * (size_t)j + 1], c = hot[3 * (size_t)j + 2];
+        float4* o = gate + 4 * (size_t)j;
+        o[0] = a;
+        o[1] = make_float4(b.x, b.y, b.z, nd.mn[0]);
+        o[2] = make_float4(c.x, c.y, c.z, nd.mn[1]);
+        o[3] = make_float4(nd.mn[2], nd.mx[0], nd.mx[1], nd.mx[2]);
+    }
+}
+
 // ---- a tree that arrives from the host (pt_upload_scene): Node[] as Accelerator.Build leaves it (Accelerator.cs:113-177)
 // What the checks guarantee: no kernel can index out of bounds through these nodes, every node hangs below the root exactly
 // once, and the leaves hold as many triangles as were uploaded.

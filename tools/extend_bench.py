@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--refill", type=int, default=0, help="idle lanes a wave collects before fetching rays (0 = the library's choice for bounce rays)")
     ap.add_argument("--coherent", action="store_true", help="primary camera rays instead of bounce rays")
     ap.add_argument("--spp", type=int, default=1, help="with --coherent: this many samples of every pixel")
+    ap.add_argument("--quant", type=int, default=2, help="node records: 0 exact 128-byte, 1 quantised 64-byte, 2 the library's choice (quantised for trees beyond L2)")
     ap.add_argument("--sort", type=int, default=0, help="experiment: order the rays by a Morton key of the origin with this many bits per axis (+ direction octant)")
     args = ap.parse_args()
 
@@ -55,6 +56,7 @@ def main():
     if args.refill:
         wf.set_option(8, args.refill)
     wf.upload_scene(mats, tris, nodes)
+    wf.set_option(9, args.quant)
     rng = np.random.RandomState(1)
     n = args.rays
 
