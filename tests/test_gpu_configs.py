@@ -221,3 +221,63 @@ def test_config3_soup_render_against_the_oracle(pa, ob):
     assert np.isfinite(imgs[0]).all() and (imgs[0] >= 0).all()
     assert np.array_equal(bits(imgs[1]), bits(imgs[0])) and np.array_equal(bits(imgs[2]), bits(imgs[0]))
     wf.close()
+
+
+# ---- whole frames at the configurations' full sizes against the oracle (not only against themselves)
+def _full_frame(pa, ob, scene, view, w, h, spp, bounces, stats=False, threads=16):
+    """Renders spp samples of the full-size frame on the GPU and with the oracle over the same arrays; returns both images and
+    both counter sets.  The oracle walks arrays the multi-threaded host mirror built (tied to the literal build elsewhere)."""
+    mats, tris, nodes = scene.arrays()
+    o = ob.Scene("")
+    o.set_built(mats, tris, nodes)
+    wf = pa.Wavefront(nee=True, rng_mode=1, traversal_stats=stats)
+    wf.upload_scene(mats, tris, nodes)
+    wf.allocate(w, h)
+    fs, _ = o.camera(view[0], view[1], w, h, use_scene=False, frames=1, samples=0)
+    wf.invoke(fs, spp=spp, max_bounces=bounces)
+    img = wf.read_image()
+    st = wf.stats()
+    wf.close()
+    osum, ost = o.render(ob.render_state(w, h), fs, ob.path_config(bounces, 1, 1), spp, threads=threads)
+    return img, st, osum / np.float32(spp), ost
+
+
+def test_headline_frame_full_size_against_the_oracle(pa, ob):
+    """Configuration 2 as bench.py times it — bundled scene, 1920x1080, 4 bounces, next-event estimation — the first 4 of its 16
+    samples per pixel at FULL size: every pixel the same bits as the oracle's, ray counts equal (8.3M paths, one batch)."""
+    from pathtracer_amd.host import Scene
+    s = Scene()
+    s.initialize_scene(11)
+    s.build(8)
+    img, st, oimg, ost = _full_frame(pa, ob, s, ((0, 2, 15), (0, 3, 0)), 1920, 1080, 4, 4)
+    assert st["stack_overflows"] == 0 and st["paths"] == 4 * 1920 * 1080
+    assert st["extend_rays"] == ost["extend_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert np.array_equal(bits(img), bits(oimg))
+
+
+def test_config3_full_size_frame_against_the_oracle(pa, ob):
+    """Configuration 3 at its full 1920x1080, 1 sample per pixel, 4 bounces, next-event estimation: the paths a small frame does
+    not take — camera rays queued pixel group by pixel group, the quantised node records, 2M-path launches — against the oracle:
+    image bits, ray counts, and the step / triangle-test counters of both traversal stages."""
+    from pathtracer_amd.host import Scene
+    s = Scene("")
+    s.generate_soup(1000000)
+    s.build(8)
+    img, st, oimg, ost = _full_frame(pa, ob, s, ((0, 0, 120), (0, 0, 0)), 1920, 1080, 1, 4, stats=True)
+    assert st["stack_overflows"] == 0
+    for k in ["extend_rays", "shadow_rays", "extend_steps", "extend_tris", "shadow_steps", "shadow_tris"]:
+        assert st[k] == ost[k], (k, st[k], ost[k])
+    assert np.array_equal(bits(img), bits(oimg))
+
+
+def test_config4_full_size_frame_against_the_oracle(pa, ob):
+    """Configuration 4 (259,600 triangles) at its full 3840x2160, 1 sample per pixel, 4 bounces, next-event estimation: image bits
+    and ray counts equal the oracle's over all 8.3M pixels."""
+    from pathtracer_amd.host import Scene
+    s = Scene()
+    s.initialize_scene_extended(11, 19)
+    s.build(8)
+    img, st, oimg, ost = _full_frame(pa, ob, s, ((0, 2, 15), (0, 3, 0)), 3840, 2160, 1, 4)
+    assert st["stack_overflows"] == 0 and st["paths"] == 3840 * 2160
+    assert st["extend_rays"] == ost["extend_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert np.array_equal(bits(img), bits(oimg))

@@ -145,6 +145,65 @@ def test_special_rays_in_the_extend_stage(ob, bundled, wf_bundled):
     assert special.sum() > 1000 and (tri >= 0).sum() > 1000
 
 
+def test_quantised_node_records(pa, ob, bundled, soup50k):
+    """The 64-byte node records (boxes on a 16-bit grid, exact leaf boxes applied at the triangles) are what the kernels walk for
+    trees beyond L2; forced on here for two small scenes.  Hits, distances, barycentrics, occlusion flags, a frame with next-event
+    estimation and the step / triangle-test counters of both traversal stages equal the oracle's restatement of that walk — and the
+    hits equal the literal C# traversal, which knows nothing of the grid.  Rays that start far outside the scene (beyond the grid's
+    reach), with tiny direction components or NaN-capable ones fall back to the exact two-wide walk in the same waves."""
+    for scene, lo, hi, view in [(bundled, (-8, 0, -8), (8, 8, 8), ((0, 2, 15), (0, 3, 0))), (soup50k, (-60, -60, -60), (60, 60, 60), ((0, 0, 120), (0, 0, 0)))]:
+        wf = make_wf(pa, scene, nee=True, rng_mode=1, traversal_stats=True)
+        wf.set_option(9, 1)
+        scene.set_quantized(1)
+        try:
+            rng = np.random.default_rng(11)
+            n = 120000
+            rays = np.zeros((n, 6), np.float32)
+            rays[:, 0:3] = rng.uniform(lo, hi, (n, 3))
+            d = rng.normal(size=(n, 3)).astype(np.float32)
+            rays[:, 3:6] = d / np.sqrt((d * d).sum(1, dtype=np.float32))[:, None]
+            far = rng.random(n) < 0.1                       # origins up to 60 scene extents away: beyond the grid's reach of 16
+            rays[far, 0:3] *= rng.uniform(1, 400, (int(far.sum()), 1)).astype(np.float32)
+            aim = -rays[far, 0:3] + rng.uniform(lo, hi, (int(far.sum()), 3)).astype(np.float32)
+            rays[far, 3:6] = aim / np.sqrt((aim * aim).sum(1, dtype=np.float32))[:, None]
+            tiny = rng.random(n) < 0.05
+            rays[tiny, 3 + rng.integers(0, 3, int(tiny.sum()))] = np.float32(1e-25)   # below the quantised walk's 1e-20
+            zero = rng.random(n) < 0.05
+            rays[zero, 3 + rng.integers(0, 3, int(zero.sum()))] = 0.0
+            wf.reset_stats()
+            g = wf.trace_closest(rays)
+            assert wf.stats()["special_rays"] > 0.08 * n
+            can = scene.intersect(rays, "canonical", threads=8)
+            lit = scene.intersect(rays, "literal", threads=8)
+            assert (g["tri"] >= 0).mean() > 0.1
+            assert np.array_equal(g["tri"], can["tri"]) and np.array_equal(bits(g["t"]), bits(can["t"])) and np.array_equal(bits(g["uv"]), bits(can["uv"]))
+            assert np.array_equal(bits(g["t"]), bits(lit["t"]))
+            differs = np.nonzero(g["tri"] != lit["tri"])[0]      # exact distance ties only, towards the smaller index
+            assert (g["tri"][differs] < lit["tri"][differs]).all() and len(differs) <= 8
+            tmax = rng.uniform(1, 80, n).astype(np.float32)
+            assert np.array_equal(wf.trace_occluded(rays, tmax), scene.occluded(rays, tmax, threads=8))
+            w, h, spp = 192, 128, 2
+            wf.allocate(w, h)
+            fs, _ = scene.camera(view[0], view[1], w, h, use_scene=False, frames=1, samples=1)
+            wf.reset_stats()
+            wf.invoke(fs, spp=spp, max_bounces=4)
+            img = wf.read_image()
+            st = wf.stats()
+            osum, ost = scene.render(ob.render_state(w, h), fs, ob.path_config(4, 1, 1), spp, threads=8)
+            assert st["stack_overflows"] == 0
+            for k in ["extend_rays", "shadow_rays", "extend_steps", "extend_tris", "shadow_steps", "shadow_tris"]:
+                assert st[k] == ost[k], (k, st[k], ost[k])
+            assert np.array_equal(bits(img), bits(osum / np.float32(spp)))
+            # and the image is the one the exact records give
+            wf.set_option(9, 0)
+            wf.allocate(w, h)
+            wf.invoke(fs, spp=spp, max_bounces=4)
+            assert np.array_equal(bits(wf.read_image()), bits(img))
+        finally:
+            scene.set_quantized(2)
+            wf.close()
+
+
 def _host_build(pa, tris, threads=4):
     from pathtracer_amd.host import Scene
     s = Scene("")
