@@ -18,6 +18,21 @@ namespace PathTracer
             [MarshalAs(UnmanagedType.ByValArray, SizeConst = 5)] public int[] Reserved;
         }
 
+        // pt_stats: sequential, no padding beyond what the field order gives (8-byte fields sit on 8-byte offsets)
+        [StructLayout(LayoutKind.Sequential)]
+        public struct Stats
+        {
+            public uint StructSize, Reserved0;           // StructSize = Marshal.SizeOf<Stats>() before pt_get_stats; the library writes no more
+            public ulong Paths, ExtendRays, ShadowRays, ExtendSteps, ExtendTris, ShadowSteps, ShadowTris, StackOverflows;
+            public uint ExtendLaunches, ShadeLaunches, ConnectLaunches, GenerateLaunches;
+            public float MsGenerate, MsExtend, MsShade, MsConnect, MsRender, MsExtendPrimary, Reserved1, Reserved2;
+            public ulong SchedInterior, SchedLeaf, SchedRefill, SpecialRays, ExtendUniqueSteps, ExtendUniqueTris, DeviceAllocations;
+        }
+
+        // PT_OPT_* keys of pt_set_option
+        public const int OptNee = 1, OptRngMode = 2, OptTraversalStats = 3, OptStageTiming = 4, OptSamplesPerBatch = 5,
+                         OptTraverseBlocksPerCu = 6, OptRefillPrimary = 7, OptRefillBounce = 8, OptQuantized = 9;
+
         [DllImport(Lib)] public static extern int pt_default_config(ref Config cfg);
         [DllImport(Lib)] public static extern int pt_create(ref Config cfg, out IntPtr ctx);
         [DllImport(Lib)] public static extern int pt_destroy(IntPtr ctx);
@@ -38,6 +53,14 @@ namespace PathTracer
         [DllImport(Lib)] public static extern int pt_trace_closest_noalloc(IntPtr ctx, float[] originDirection, int n, int[] tri, float[] t, float[] uv);
         [DllImport(Lib)] public static extern int pt_trace_occluded(IntPtr ctx, float[] originDirection, float[] tmax, int n, byte[] occluded);
         [DllImport(Lib)] public static extern int pt_set_option(IntPtr ctx, int key, int value);
+        [DllImport(Lib)] public static extern int pt_get_stats(IntPtr ctx, ref Stats stats);       // set stats.StructSize first
+        [DllImport(Lib)] public static extern int pt_reset_stats(IntPtr ctx);
+        [DllImport(Lib)] public static extern int pt_generate_rays(IntPtr ctx, ref State.FrameState fs, int n, float[] originDirection, uint[] pixel);
+        [DllImport(Lib)] public static extern int pt_bench_extend(IntPtr ctx, float[] originDirection, int n, int iters, out float avgMs, int[] tri, float[] t);
+        [DllImport(Lib)] public static extern int pt_stream(IntPtr ctx, out IntPtr hipStream);
+        // one process per GPU (TileRank / TileWorld): the rank-local accumulator for a gather the host runs itself, and its assembly
+        [DllImport(Lib)] public static extern int pt_accum_device(IntPtr ctx, out IntPtr devicePtr, out ulong nSlotsPadded, out uint samples);
+        [DllImport(Lib)] public static extern int pt_assemble_tiles(IntPtr ctx, IntPtr gatheredDevice, int world, uint samples, float[] rgba);
 
         public static void Check(IntPtr ctx, int status)
         {

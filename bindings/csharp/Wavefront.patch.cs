@@ -39,5 +39,17 @@ class Wavefront : IDisposable
         Native.Check(Context, Native.pt_render(Context, ref this.frame, 1, 10));
     }
 
+    public void ReadImage(float[] rgba)                  // the rgba32f image the shaders used to write (Image.cs:7-19): width * height * 4
+    {                                                    // floats, row 0 = bottom like gl_FragCoord; waits for the frame
+        Native.Check(Context, Native.pt_read_image(Context, rgba));
+    }
+
+    public Native.Stats Stats()
+    {
+        var s = new Native.Stats { StructSize = (uint)Marshal.SizeOf<Native.Stats>() };
+        Native.Check(Context, Native.pt_get_stats(Context, ref s));
+        return s;
+    }
+
     public void Dispose() => Native.pt_destroy(Context);
 }

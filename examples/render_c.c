@@ -88,6 +88,7 @@ int main(int argc, char** argv) {
         fclose(f);
     }
     pt_stats st;
+    st.struct_size = (uint32_t)sizeof(st);
     GPU(pt_get_stats(ctx, &st));
     printf("%dx%d %d spp on %d GPU context(s): %llu extend rays, %llu shadow rays, checksum %016llx\n", width, height, spp, devices, (unsigned long long)st.extend_rays,
            (unsigned long long)st.shadow_rays, (unsigned long long)h);

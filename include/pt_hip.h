@@ -76,6 +76,9 @@ enum { PT_GROUP_SAME_DEVICE = 1 /* rehearsal on a single GPU: all device_count m
                                    itself): exercises library loading, communicator set-up and the send/receive calls */ };
 
 typedef struct pt_stats {
+    uint32_t struct_size;       /* IN: sizeof(pt_stats) as the caller was compiled (the struct grows at its end from version to
+                                   version); pt_get_stats writes no more than this many bytes and stores the count it wrote here */
+    uint32_t reserved0;
     uint64_t paths;             /* primary rays generated */
     uint64_t extend_rays;       /* rays traced by extend (primary + bounce) */
     uint64_t shadow_rays;       /* rays traced by connect */
@@ -97,6 +100,8 @@ typedef struct pt_stats {
     /* extend stage, traversal_stats only: node records / triangle records fetched, counting the lanes of one wave instruction
      * that ask for the same record once (the vector memory pipeline serves them together): what the stage's loads cost */
     uint64_t extend_unique_steps, extend_unique_tris;
+    uint64_t device_allocations; /* hipMalloc calls the library has made in this process so far (all contexts): unchanged across a
+                                   call means the call allocated no device memory */
 } pt_stats;
 
 /* ---- lifetime --------------------------------------------------------------
@@ -146,12 +151,14 @@ int pt_trace_closest(pt_ctx* ctx, const float* o_d, int32_t n, int32_t* tri, flo
 /* Any hit with 0 < t < tmax[i] (the connect stage's query).  No reference counterpart: the reference has no shadow rays. */
 int pt_trace_occluded(pt_ctx* ctx, const float* o_d, const float* tmax, int32_t n, uint8_t* occluded);
 
-/* pt_trace_closest for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments and results as
- * pt_trace_closest, but the rays and hits are staged in a fixed device array of the library (40 bytes per ray,
- * PT_NOALLOC_MAX_RAYS rays = 2.5 MiB held on every GPU the library runs on until the process ends) instead of buffers
- * allocated per call: the call makes no hipMalloc / hipFree.  n > PT_NOALLOC_MAX_RAYS is PT_E_INVALID_ARG.  All calls
- * on one GPU share that array: calls that overlap on one GPU (two contexts, two threads) race. */
+/* pt_trace_closest for callers that cannot allocate device memory: tight serving loops, harnesses that forbid hipMalloc,
+ * hosts that are capturing a HIP graph on ANOTHER stream of the process (an allocation there would invalidate the capture).
+ * It has no counterpart in the reference.  Same arguments and results as pt_trace_closest, but the rays and hits are staged
+ * in a fixed device array of the library (40 bytes per ray, PT_NOALLOC_MAX_RAYS rays = 2.5 MiB held on every GPU the library
+ * runs on until the process ends) instead of buffers allocated per call: the call makes no hipMalloc / hipFree.  The call
+ * itself copies from and to the caller's host arrays on the context's stream and waits for it: it blocks, and it cannot be
+ * recorded into a graph.  n > PT_NOALLOC_MAX_RAYS is PT_E_INVALID_ARG.  All calls on one GPU share that array: calls that
+ * overlap on one GPU (two contexts, two threads) race. */
 #define PT_NOALLOC_MAX_RAYS 65536
 int pt_trace_closest_noalloc(pt_ctx* ctx, const float* o_d, int32_t n, int32_t* tri, float* t, float* uv);
 
@@ -164,6 +171,7 @@ int pt_generate_rays(pt_ctx* ctx, const void* frame_state112, int32_t n, float* 
  * tri / t (may be NULL) receive the hits of the last launch. */
 int pt_bench_extend(pt_ctx* ctx, const float* o_d, int32_t n, int32_t iters, float* avg_ms, int32_t* tri, float* t);
 
+/* out->struct_size must hold the caller's sizeof(pt_stats) (at least 16); fields beyond it are not written. */
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
 int pt_reset_stats(pt_ctx* ctx);
 

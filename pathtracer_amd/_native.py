@@ -23,7 +23,8 @@ class pt_config(C.Structure):
 
 
 class pt_stats(C.Structure):
-    _fields_ = [("paths", C.c_uint64), ("extend_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
+                ("paths", C.c_uint64), ("extend_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("extend_steps", C.c_uint64), ("extend_tris", C.c_uint64), ("shadow_steps", C.c_uint64),
                 ("shadow_tris", C.c_uint64), ("stack_overflows", C.c_uint64),
                 ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("connect_launches", C.c_uint32),
@@ -31,10 +32,11 @@ class pt_stats(C.Structure):
                 ("ms_generate", C.c_float), ("ms_extend", C.c_float), ("ms_shade", C.c_float), ("ms_connect", C.c_float),
                 ("ms_render", C.c_float), ("ms_extend_primary", C.c_float), ("reserved", C.c_float * 2),
                 ("sched_interior", C.c_uint64), ("sched_leaf", C.c_uint64), ("sched_refill", C.c_uint64),
-                ("special_rays", C.c_uint64), ("extend_unique_steps", C.c_uint64), ("extend_unique_tris", C.c_uint64)]
+                ("special_rays", C.c_uint64), ("extend_unique_steps", C.c_uint64), ("extend_unique_tris", C.c_uint64),
+                ("device_allocations", C.c_uint64)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_ if n not in ("reserved", "reserved0", "struct_size")}
 
 
 PT_OPT_NEE, PT_OPT_RNG_MODE, PT_OPT_TRAVERSAL_STATS, PT_OPT_STAGE_TIMING, PT_OPT_SAMPLES_PER_BATCH, PT_OPT_TRAVERSE_BLOCKS_PER_CU = 1, 2, 3, 4, 5, 6

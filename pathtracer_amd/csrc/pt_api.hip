@@ -144,7 +144,7 @@ int allocQueues(pt_ctx* c, uint32_t capacity) {
     float4** cols[] = {&c->q.o[0], &c->q.o[1], &c->q.d[0], &c->q.d[1], &c->q.T[0], &c->q.T[1], &c->q.hit, &c->q.so, &c->q.sd, &c->q.sc, &c->q.plane};
     for (float4** col : cols) {
         void* p = nullptr;
-        const hipError_t e = hipMalloc(&p, (size_t)capacity * sizeof(float4));
+        const hipError_t e = ptMalloc(&p, (size_t)capacity * sizeof(float4));
         if (e != hipSuccess) {
             for (void* m : c->qmem) (void)hipFree(m);
             c->qmem.clear();
@@ -452,7 +452,7 @@ static int impl_create_single(const pt_config* cfg, pt_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_connect, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_shaded, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_connected, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctl, sizeof(Ctl));
+    if (e == hipSuccess) e = ptMalloc((void**)&c->d_ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipMemset(c->d_ctl, 0, sizeof(Ctl));
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
@@ -544,7 +544,7 @@ static int impl_resize(pt_ctx* c, int32_t width, int32_t height) {
         HIPCHECK(c, hipSetDevice(first->cfg.device));
         if (g->d_gather) { (void)hipFree(g->d_gather); g->d_gather = nullptr; }
         g->gather_slots = (size_t)std::max(1u, first->slots_padded);
-        HIPCHECK(c, hipMalloc((void**)&g->d_gather, g->gather_slots * g->members.size() * sizeof(float4)));
+        HIPCHECK(c, ptMalloc((void**)&g->d_gather, g->gather_slots * g->members.size() * sizeof(float4)));
         c->width = width;
         c->height = height;
         return PT_OK;
@@ -566,8 +566,8 @@ static int impl_resize(pt_ctx* c, int32_t width, int32_t height) {
         const uint32_t gx = g % gw, gy = g / gw;
         c->local_pixels += (uint64_t)std::min(8u, (uint32_t)width - gx * 8u) * std::min(8u, (uint32_t)height - gy * 8u);
     }
-    HIPCHECK(c, hipMalloc((void**)&c->d_sum, (size_t)std::max(1u, c->slots_padded) * sizeof(float4)));
-    HIPCHECK(c, hipMalloc((void**)&c->d_image, (size_t)width * height * sizeof(float4)));
+    HIPCHECK(c, ptMalloc((void**)&c->d_sum, (size_t)std::max(1u, c->slots_padded) * sizeof(float4)));
+    HIPCHECK(c, ptMalloc((void**)&c->d_image, (size_t)width * height * sizeof(float4)));
     HIPCHECK(c, hipMemset(c->d_sum, 0, (size_t)std::max(1u, c->slots_padded) * sizeof(float4)));
     c->samples_accumulated = 0;
     c->has_rs = false;
@@ -871,21 +871,21 @@ static int traceCommon(pt_ctx* c, bool anyhit, const float* o_d, const float* tm
     int rc = PT_OK;
     auto cleanup = [&]() { (void)hipFree(d_rays); (void)hipFree(d_tmax); (void)hipFree(d_t); (void)hipFree(d_uv); (void)hipFree(d_tri); (void)hipFree(d_occ); };
 #define TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); FAIL(c, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s", #call, hipGetErrorString(_e)); } } while (0)
-    TRY(hipMalloc((void**)&d_rays, (size_t)n * 24));
+    TRY(ptMalloc((void**)&d_rays, (size_t)n * 24));
     TRY(hipMemcpyAsync(d_rays, o_d, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, 0ull);
     if (anyhit) {
-        TRY(hipMalloc((void**)&d_tmax, (size_t)n * 4));
-        TRY(hipMalloc((void**)&d_occ, (size_t)n));
+        TRY(ptMalloc((void**)&d_tmax, (size_t)n * 4));
+        TRY(ptMalloc((void**)&d_occ, (size_t)n));
         TRY(hipMemcpyAsync(d_tmax, tmax, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
         TraceSource src{d_rays, d_tmax, nullptr, nullptr, nullptr, d_occ};
         launchTrace(c, true, src, n);
         TRY(hipGetLastError());
         TRY(hipMemcpyAsync(occ, d_occ, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     } else {
-        TRY(hipMalloc((void**)&d_tri, (size_t)n * 4));
-        TRY(hipMalloc((void**)&d_t, (size_t)n * 4));
-        if (uv) TRY(hipMalloc((void**)&d_uv, (size_t)n * 8));
+        TRY(ptMalloc((void**)&d_tri, (size_t)n * 4));
+        TRY(ptMalloc((void**)&d_t, (size_t)n * 4));
+        if (uv) TRY(ptMalloc((void**)&d_uv, (size_t)n * 8));
         TraceSource src{d_rays, nullptr, d_tri, d_t, d_uv, nullptr};
         launchTrace(c, false, src, n);
         TRY(hipGetLastError());
@@ -1044,11 +1044,11 @@ static int impl_build_bvh(pt_ctx* c, const void* triangles_in, int32_t n_tri, vo
     auto cleanup = [&]() { (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_nodes); };
 #define TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); FAIL(c, (_e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "%s failed: %s", #call, hipGetErrorString(_e)); } } while (0)
     if (n_tri) {
-        TRY(hipMalloc((void**)&d_in, (size_t)n_tri * 112));
-        TRY(hipMalloc((void**)&d_out, (size_t)n_tri * 112));
+        TRY(ptMalloc((void**)&d_in, (size_t)n_tri * 112));
+        TRY(ptMalloc((void**)&d_out, (size_t)n_tri * 112));
         TRY(hipMemcpyAsync(d_in, triangles_in, (size_t)n_tri * 112, hipMemcpyHostToDevice, c->stream));
     }
-    TRY(hipMalloc((void**)&d_nodes, (size_t)need * 32));
+    TRY(ptMalloc((void**)&d_nodes, (size_t)need * 32));
     hipEvent_t a = getEvent(c), b = getEvent(c);
     if (a) (void)hipEventRecord(a, c->stream);
     uint32_t nn = 0, levels = 0;
@@ -1111,20 +1111,20 @@ struct SceneWork {
 // except for two small read-backs that size the allocations.
 static int repackOnDevice(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn, const void* materials, int32_t n_mat) {
     const size_t flagsLen = std::max<size_t>(std::max<size_t>(n, nn), 1);
-    TRY(hipMalloc((void**)&w.d_flagA, flagsLen * 4));
-    TRY(hipMalloc((void**)&w.d_idxA, flagsLen * 4));
-    TRY(hipMalloc((void**)&w.d_flagB, flagsLen * 4));
-    TRY(hipMalloc((void**)&w.d_idxB, flagsLen * 4));
-    TRY(hipMalloc((void**)&w.d_bad, 4));
+    TRY(ptMalloc((void**)&w.d_flagA, flagsLen * 4));
+    TRY(ptMalloc((void**)&w.d_idxA, flagsLen * 4));
+    TRY(ptMalloc((void**)&w.d_flagB, flagsLen * 4));
+    TRY(ptMalloc((void**)&w.d_idxB, flagsLen * 4));
+    TRY(ptMalloc((void**)&w.d_bad, 4));
     TRY(hipMemsetAsync(w.d_bad, 0, 4, c->stream));
     if (n_mat) {
-        TRY(hipMalloc(&w.mats, (size_t)n_mat * 48));
+        TRY(ptMalloc(&w.mats, (size_t)n_mat * 48));
         TRY(hipMemcpyAsync(w.mats, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, c->stream));
     }
     // ---- triangles: hot / cold records, the light table
     if (n) {
-        TRY(hipMalloc(&w.hot, (size_t)n * 48));
-        TRY(hipMalloc(&w.cold, (size_t)n * 48));
+        TRY(ptMalloc(&w.hot, (size_t)n * 48));
+        TRY(ptMalloc(&w.cold, (size_t)n * 48));
         hipLaunchKernelGGL(ptrepack::k_triangles, dim3(launchGrid(n)), dim3(256), 0, c->stream, w.d_sorted, n, (const float4*)w.mats, n_mat,
                            (float4*)w.hot, (float4*)w.cold, w.d_flagA, w.d_bad);
         TRY(ptrepack::exclusiveScan(c->stream, w.d_flagA, w.d_idxA, n, &w.tmp, &w.tmpBytes));
@@ -1136,7 +1136,7 @@ static int repackOnDevice(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn, cons
         w.nLights = w.rbTri[0] + w.rbTri[1];
         if (w.nLights) {
             // rows in triangle order; the running sum rounds as a CPU loop over the triangles would (d_bad is free again: it receives the total)
-            TRY(hipMalloc(&w.lights, (size_t)w.nLights * 3 * sizeof(float4)));
+            TRY(ptMalloc(&w.lights, (size_t)w.nLights * 3 * sizeof(float4)));
             float* const areas = (float*)w.d_flagB;   // free until the node flags are formed
             hipLaunchKernelGGL(ptrepack::k_light_rows, dim3(launchGrid(n)), dim3(256), 0, c->stream, w.d_sorted, n, w.d_flagA, w.d_idxA, (float4*)w.lights, areas);
             hipLaunchKernelGGL(ptrepack::k_light_sums, dim3(1), dim3(64), 0, c->stream, areas, (float4*)w.lights, w.nLights, (float*)w.d_bad);
@@ -1156,20 +1156,20 @@ static int repackOnDevice(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn, cons
     const uint32_t nQuads = v[0] + v[1], nBig = v[2] + v[3];
     w.nQuads = nQuads;
     if (nBig >= PT_LEAF_MAX_FIRST) FAIL(c, PT_E_BAD_BVH, "%u leaves of more than %d triangles", nBig, PT_LEAF_MAX_COUNT);
-    if (nn > 1) TRY(hipMalloc(&w.pairs, (size_t)(nn - 1) * 32));
-    if (nQuads) TRY(hipMalloc(&w.quads, (size_t)nQuads * 128));
-    if (nBig) TRY(hipMalloc(&w.big, (size_t)nBig * 8));
+    if (nn > 1) TRY(ptMalloc(&w.pairs, (size_t)(nn - 1) * 32));
+    if (nQuads) TRY(ptMalloc(&w.quads, (size_t)nQuads * 128));
+    if (nBig) TRY(ptMalloc(&w.big, (size_t)nBig * 8));
     hipLaunchKernelGGL(ptrepack::k_records, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_idxA, w.d_idxB, w.d_flagB, (float4*)w.pairs,
                        (float4*)w.quads, (uint2*)w.big);
     // the same records in 64 bytes on the scene's grid, and the triangles with their leaves' boxes beside them
-    TRY(hipMalloc((void**)&w.d_qbad, 4));
+    TRY(ptMalloc((void**)&w.d_qbad, 4));
     TRY(hipMemsetAsync(w.d_qbad, 0, 4, c->stream));
     if (nQuads) {
-        TRY(hipMalloc(&w.qquads, (size_t)nQuads * 64));
+        TRY(ptMalloc(&w.qquads, (size_t)nQuads * 64));
         hipLaunchKernelGGL(ptrepack::k_qrecords, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, w.d_idxA, w.d_idxB, (uint4*)w.qquads, w.d_qbad);
     }
     if (n) {
-        TRY(hipMalloc(&w.gate, (size_t)n * 64));
+        TRY(ptMalloc(&w.gate, (size_t)n * 64));
         hipLaunchKernelGGL(ptrepack::k_tri_gate, dim3(launchGrid(nn)), dim3(256), 0, c->stream, w.bn, nn, (const float4*)w.hot, (float4*)w.gate);
     }
     TRY(hipMemcpyAsync(&w.qbad, w.d_qbad, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1227,11 +1227,11 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
     const uint32_t n = (uint32_t)n_tri;
     SceneWork w(c);
     if (n) {
-        TRY(hipMalloc((void**)&w.d_in, (size_t)n * 112));
-        TRY(hipMalloc((void**)&w.d_sorted, (size_t)n * 112));
+        TRY(ptMalloc((void**)&w.d_in, (size_t)n * 112));
+        TRY(ptMalloc((void**)&w.d_sorted, (size_t)n * 112));
         TRY(hipMemcpyAsync(w.d_in, triangles_in, (size_t)n * 112, hipMemcpyHostToDevice, c->stream));
     }
-    TRY(hipMalloc((void**)&w.d_nodes, (size_t)need * 32));
+    TRY(ptMalloc((void**)&w.d_nodes, (size_t)need * 32));
     w.ea = getEvent(c);
     w.eb = getEvent(c);
     if (w.ea) (void)hipEventRecord(w.ea, c->stream);
@@ -1269,7 +1269,7 @@ static int uploadOne(pt_ctx* c, const void* materials, int32_t n_mat, const void
     SceneWork w(c);
     if (nn == 0) {
         if (n_mat) {
-            TRY(hipMalloc(&w.mats, (size_t)n_mat * 48));
+            TRY(ptMalloc(&w.mats, (size_t)n_mat * 48));
             TRY(hipMemcpyAsync(w.mats, materials, (size_t)n_mat * 48, hipMemcpyHostToDevice, c->stream));
             TRY(hipStreamSynchronize(c->stream));
         }
@@ -1279,13 +1279,13 @@ static int uploadOne(pt_ctx* c, const void* materials, int32_t n_mat, const void
     }
     if ((nn & 1u) == 0u) FAIL(c, PT_E_BAD_BVH, "node count %d is even: nodes are a root plus sibling pairs", n_nodes);
     const HostNode* hn = (const HostNode*)nodes;
-    TRY(hipMalloc((void**)&w.d_sorted, (size_t)n * 112));
-    TRY(hipMalloc((void**)&w.d_nodes, (size_t)nn * 32));
-    TRY(hipMalloc((void**)&w.bn, (size_t)nn * sizeof(ptbuild::BNode)));
-    TRY(hipMalloc((void**)&w.d_parent, (size_t)nn * 4));
-    TRY(hipMalloc((void**)&w.d_refs, (size_t)(nn / 2 + 1) * 4));
-    for (int k = 0; k < 2; k++) { TRY(hipMalloc((void**)&w.d_anc[k], (size_t)nn * 4)); TRY(hipMalloc((void**)&w.d_dep[k], (size_t)nn * 4)); }
-    TRY(hipMalloc((void**)&w.d_check, sizeof(ptrepack::UploadCheck)));
+    TRY(ptMalloc((void**)&w.d_sorted, (size_t)n * 112));
+    TRY(ptMalloc((void**)&w.d_nodes, (size_t)nn * 32));
+    TRY(ptMalloc((void**)&w.bn, (size_t)nn * sizeof(ptbuild::BNode)));
+    TRY(ptMalloc((void**)&w.d_parent, (size_t)nn * 4));
+    TRY(ptMalloc((void**)&w.d_refs, (size_t)(nn / 2 + 1) * 4));
+    for (int k = 0; k < 2; k++) { TRY(ptMalloc((void**)&w.d_anc[k], (size_t)nn * 4)); TRY(ptMalloc((void**)&w.d_dep[k], (size_t)nn * 4)); }
+    TRY(ptMalloc((void**)&w.d_check, sizeof(ptrepack::UploadCheck)));
     TRY(hipMemcpyAsync(w.d_nodes, nodes, (size_t)nn * 32, hipMemcpyHostToDevice, c->stream));
     TRY(hipMemcpyAsync(w.d_sorted, triangles, (size_t)n * 112, hipMemcpyHostToDevice, c->stream));
     ptrepack::UploadCheck chk{};
@@ -1344,14 +1344,29 @@ static int impl_upload_scene(pt_ctx* c, const void* materials, int32_t n_mat, co
     return uploadOne(c, materials, n_mat, triangles, n_tri, nodes, n_nodes);
 }
 
+// The statistics in the library's own (current) struct; pt_get_stats copies as much of it as the caller's struct holds.
+static int gatherStats(pt_ctx* c, pt_stats* out);
+
 int pt_get_stats(pt_ctx* c, pt_stats* out) {
     if (!c || !out) return PT_E_INVALID_ARG;
+    const uint32_t room = out->struct_size;
+    if (room < 16u) FAIL(c, PT_E_INVALID_ARG, "pt_get_stats: pt_stats.struct_size is %u; set it to sizeof(pt_stats) before the call", room);
+    pt_stats full{};
+    const int rc = gatherStats(c, &full);
+    if (rc != PT_OK) return rc;
+    const uint32_t n = std::min<uint32_t>(room, (uint32_t)sizeof(pt_stats));
+    full.struct_size = n;
+    memcpy(out, &full, n);
+    return PT_OK;
+}
+
+static int gatherStats(pt_ctx* c, pt_stats* out) {
     if (c->group) {
         // ray and step counts add up over the GPUs; times are the slowest GPU's; launch counts are per GPU
         pt_stats total{};
         for (size_t i = 0; i < c->group->members.size(); i++) {
             pt_stats s;
-            const int rc = pt_get_stats(c->group->members[i], &s);
+            const int rc = gatherStats(c->group->members[i], &s);
             if (rc != PT_OK) { c->err = c->group->members[i]->err; return rc; }
             if (i == 0) { total = s; continue; }
             total.paths += s.paths; total.extend_rays += s.extend_rays; total.shadow_rays += s.shadow_rays;
@@ -1385,6 +1400,7 @@ int pt_get_stats(pt_ctx* c, pt_stats* out) {
     s.special_rays = ctl.special_rays;
     s.extend_unique_steps = ctl.unique_steps;
     s.extend_unique_tris = ctl.unique_tris;
+    s.device_allocations = ptAllocCount().load(std::memory_order_relaxed);
     *out = s;
     return PT_OK;
 }

@@ -21,12 +21,19 @@
 //     nodes; per level they cost a pass over all primitives and global atomics per primitive, per thread
 //     they cost a few dozen primitives that stay in cache.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
 #include <cstring>
 #include <vector>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
+
+// Every device allocation of the library goes through here, so that the number of allocations a call made can be read back
+// (pt_stats.device_allocations): that is how a test shows that an entry point allocates nothing.
+inline std::atomic<unsigned long long>& ptAllocCount() { static std::atomic<unsigned long long> n{0}; return n; }
+template <class T>
+inline hipError_t ptMalloc(T** p, size_t bytes) { ptAllocCount().fetch_add(1, std::memory_order_relaxed); return hipMalloc((void**)p, bytes); }
 
 namespace ptbuild {
 
@@ -832,25 +839,25 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     const uint32_t nTiles = (nn + PTB_BLOCK - 1u) / PTB_BLOCK, tiles = nTiles > 4096u ? (nTiles + 4095u) / 4096u : 1u, tileGrid = (nTiles + tiles - 1u) / tiles;
     const uint32_t initKeys[6] = {PTB_KEY_POS_INF, PTB_KEY_POS_INF, PTB_KEY_POS_INF, PTB_KEY_NEG_INF, PTB_KEY_NEG_INF, PTB_KEY_NEG_INF};
 
-    PTB_TRY(hipMalloc((void**)&pmin, (size_t)nn * 16));
-    PTB_TRY(hipMalloc((void**)&pmax, (size_t)nn * 16));
-    PTB_TRY(hipMalloc((void**)&cent, (size_t)nn * 16));
+    PTB_TRY(ptMalloc((void**)&pmin, (size_t)nn * 16));
+    PTB_TRY(ptMalloc((void**)&pmax, (size_t)nn * 16));
+    PTB_TRY(ptMalloc((void**)&cent, (size_t)nn * 16));
     for (int k = 0; k < 2; k++) {
-        PTB_TRY(hipMalloc((void**)&order[k], (size_t)nn * 4));
-        PTB_TRY(hipMalloc((void**)&bins[k], (size_t)nn));
-        PTB_TRY(hipMalloc((void**)&active[k], (size_t)maxActive * 4));
+        PTB_TRY(ptMalloc((void**)&order[k], (size_t)nn * 4));
+        PTB_TRY(ptMalloc((void**)&bins[k], (size_t)nn));
+        PTB_TRY(ptMalloc((void**)&active[k], (size_t)maxActive * 4));
     }
-    PTB_TRY(hipMalloc((void**)&seg, ((size_t)nn + PTB_BLOCK) * 4));
-    PTB_TRY(hipMalloc((void**)&sortb, (size_t)maxActive * 4));
-    PTB_TRY(hipMalloc((void**)&sorte, (size_t)maxActive * 4));
-    PTB_TRY(hipMalloc((void**)&rootk, 6 * 4));
-    PTB_TRY(hipMalloc((void**)&small, (size_t)maxActive * 4));
-    PTB_TRY(hipMalloc((void**)&largeRank, (size_t)maxLarge * 4));
-    PTB_TRY(hipMalloc((void**)&chunkOwner, (size_t)maxChunks * 4));
-    PTB_TRY(hipMalloc((void**)&chunkCnt, (size_t)maxChunks * PTB_BINS * 4));
-    PTB_TRY(hipMalloc((void**)&nodes, (size_t)maxNodes * sizeof(BNode)));
-    PTB_TRY(hipMalloc((void**)&sp, (size_t)maxActive * sizeof(Split)));
-    PTB_TRY(hipMalloc((void**)&ctr, sizeof(Counters)));
+    PTB_TRY(ptMalloc((void**)&seg, ((size_t)nn + PTB_BLOCK) * 4));
+    PTB_TRY(ptMalloc((void**)&sortb, (size_t)maxActive * 4));
+    PTB_TRY(ptMalloc((void**)&sorte, (size_t)maxActive * 4));
+    PTB_TRY(ptMalloc((void**)&rootk, 6 * 4));
+    PTB_TRY(ptMalloc((void**)&small, (size_t)maxActive * 4));
+    PTB_TRY(ptMalloc((void**)&largeRank, (size_t)maxLarge * 4));
+    PTB_TRY(ptMalloc((void**)&chunkOwner, (size_t)maxChunks * 4));
+    PTB_TRY(ptMalloc((void**)&chunkCnt, (size_t)maxChunks * PTB_BINS * 4));
+    PTB_TRY(ptMalloc((void**)&nodes, (size_t)maxNodes * sizeof(BNode)));
+    PTB_TRY(ptMalloc((void**)&sp, (size_t)maxActive * sizeof(Split)));
+    PTB_TRY(ptMalloc((void**)&ctr, sizeof(Counters)));
     PTB_TRY(hipMemcpyAsync(rootk, initKeys, sizeof(initKeys), hipMemcpyHostToDevice, stream));
     PTB_TRY(hipMemsetAsync(seg, 0xFF, ((size_t)nn + PTB_BLOCK) * 4, stream));
     PTB_TRY(hipMemsetAsync(bins[0], 0, nn, stream));
@@ -864,7 +871,7 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
     if (n) {
         // temporary storage of the segmented sort, sized for the worst case once
         PTB_TRY(rocprim::segmented_radix_sort_pairs(nullptr, tmpBytes, bins[0], bins[1], order[0], order[1], n, maxActive, sortb, sorte, 0, 3, stream));
-        PTB_TRY(hipMalloc(&tmp, tmpBytes ? tmpBytes : 16));
+        PTB_TRY(ptMalloc(&tmp, tmpBytes ? tmpBytes : 16));
     }
     while (nActive > 0) {
         Counters z{};

@@ -280,7 +280,7 @@ inline hipError_t exclusiveScan(hipStream_t stream, const uint32_t* in, uint32_t
     if (need > *tmpBytes) {
         (void)hipFree(*tmp);
         *tmp = nullptr;
-        e = hipMalloc(tmp, need);
+        e = ptMalloc(tmp, need);
         if (e != hipSuccess) return e;
         *tmpBytes = need;
     }

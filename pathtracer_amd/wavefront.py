@@ -161,6 +161,7 @@ class Wavefront:
 
     def stats(self):
         s = _native.pt_stats()
+        s.struct_size = C.sizeof(_native.pt_stats)
         self._check(self._lib.pt_get_stats(self._h, C.byref(s)))
         return s.as_dict()
 

@@ -313,6 +313,47 @@ def test_csharp_shim_matches_the_header():
     snake = lambda f: re.sub(r"(?<!^)([A-Z])", r"_\1", f).lower()
     assert [snake(f) for f in fields] == [n for n, _ in _native.pt_config._fields_]
     assert "SizeConst = 5" in native and ctypes.sizeof(_native.pt_config) == 4 * (len(fields) - 1 + 5)
+    # every function the header declares has an import
+    assert sorted(c_params) == sorted(_native.PT_HIP_SYMBOLS), "pathtracer_amd/_native.py's symbol list and pt_hip.h disagree"
+    assert sorted(fn for fn, _ in imports) == sorted(c_params), sorted(set(c_params) - {fn for fn, _ in imports})
+    # the Stats struct has pt_stats' fields, types and order
+    stats = re.search(r"public struct Stats\s*\{(.*?)\n        \}", native, flags=re.S).group(1)
+    stats = re.sub(r"//[^\n]*", "", stats)
+    cs_fields = []
+    for ty, names in re.findall(r"public (uint|ulong|float) ([^;]*);", stats):
+        cs_fields += [(n.strip(), ty) for n in names.split(",")]
+    want = []
+    for name, ctype in _native.pt_stats._fields_:
+        if name == "reserved":
+            want += [("reserved1", "float"), ("reserved2", "float")]
+        else:
+            want.append((name, {ctypes.c_uint32: "uint", ctypes.c_uint64: "ulong", ctypes.c_float: "float"}[ctype]))
+    assert [(snake(n), t) for n, t in cs_fields] == want
+    # the option keys
+    for key, value in re.findall(r"PT_OPT_([A-Z_]+) = (\d+)", header):
+        camel = "Opt" + "".join(w.capitalize() for w in key.split("_"))
+        assert re.search(rf"\b{camel} = {value}\b", native), camel
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """pt_config and pt_stats as the Python binding (and, through it, the C# shim) lays them out, against what a C compiler makes of
+    include/pt_hip.h: size and the offset of every field."""
+    from pathtracer_amd import _native
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pt_hip.h"', 'int main(void) {']
+    for cname, st in (("pt_config", _native.pt_config), ("pt_stats", _native.pt_stats)):
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for name, _ in st._fields_:
+            lines.append(f'printf("{cname}.{name} %zu\\n", offsetof({cname}, {name}));')
+    lines.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, st in (("pt_config", _native.pt_config), ("pt_stats", _native.pt_stats)):
+        assert int(out[cname]) == ctypes.sizeof(st)
+        for name, _ in st._fields_:
+            assert int(out[f"{cname}.{name}"]) == getattr(st, name).offset, (cname, name)
 
 
 def test_headers_are_plain_c(tmp_path):

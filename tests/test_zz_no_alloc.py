@@ -39,3 +39,33 @@ def test_noalloc_trace_equals_trace_closest(bundled):
     assert wf.trace_closest_noalloc(np.zeros((0, 6), np.float32))["tri"].size == 0
     assert wf.stats()["stack_overflows"] == 0
     wf.close()
+
+
+def test_noalloc_trace_allocates_nothing(bundled):
+    """The property the entry point exists for: across several calls the library's count of device allocations
+    (pt_stats.device_allocations: every hipMalloc of the library passes one wrapper) does not move and the device's free memory
+    is the same to the byte, while pt_trace_closest moves the count with every call.  Also through a context over two
+    members (routed to its first member)."""
+    import torch
+    import pathtracer_amd as pa
+    mats, tris, nodes = bundled.arrays()
+    rng = np.random.default_rng(29)
+    for kw in ({}, {"device_count": 2, "group_flags": 1}):      # 1 = PT_GROUP_SAME_DEVICE
+        wf = pa.Wavefront(**kw)
+        wf.upload_scene(mats, tris, nodes)
+        rays = _rays(rng, 4096)
+        want = wf.trace_closest(rays)
+        wf.trace_closest_noalloc(rays)                           # warm-up: code objects, the first use of the staging array
+        torch.cuda.synchronize()
+        n0, free0 = wf.stats()["device_allocations"], torch.cuda.mem_get_info()[0]
+        for n in (4096, 65536, 17):
+            got = wf.trace_closest_noalloc(rays[:n] if n <= 4096 else _rays(rng, n))
+            if n <= 4096:
+                assert np.array_equal(got["tri"], want["tri"][:n])
+        torch.cuda.synchronize()
+        n1, free1 = wf.stats()["device_allocations"], torch.cuda.mem_get_info()[0]
+        assert n1 == n0, f"{n1 - n0} device allocations during pt_trace_closest_noalloc"
+        assert free1 == free0
+        wf.trace_closest(rays)
+        assert wf.stats()["device_allocations"] > n1, "the counter must see pt_trace_closest's per-call buffers"
+        wf.close()
