@@ -42,10 +42,19 @@ WORKLOADS = {
     "c5": ("4,026 instanced bunnies flattened (20.0M triangles), 3840x2160, 1024 spp in steps of 8, 8 bounces, NEE", 3840, 2160, 8, 8, 1),
 }
 
-# The roof that binds the traversal kernels (tools/micro/ta_rate.hip, profiles/r02_micro_ta_rate.txt): a CU's vector memory
-# pipeline returns about one lane's 16-byte load per clock, however the addresses fall (random lines, one line per lane, or fully
-# contiguous); only lanes of one instruction that ask for the SAME 16 bytes are served together.  256 CUs x 16 B x 2.4 GHz.
-VMEM_PEAK_GBS = 256 * 16 * 2.4e9 / 1e9
+# Vector memory.  A CU's texture path returns 64 bytes per clock when the lanes of a wave instruction cover whole cache lines
+# (tools/micro/gather_rate.hip: 1,152-byte rows gathered by whole waves read at 115-127 GB/s per CU = 30-32 TB/s from L2,
+# profiles/r03_micro_gather_rate*.txt): 256 CUs x 64 B x 2.4 GHz is the roof.  The traversal's own pattern — every lane fetches the
+# record of its own ray, 64 different lines per wave instruction — is served at one lane-load (16 B) per clock and CU,
+# 9.8 TB/s nominal and 9.5-9.7 measured from L2, 4-5 from the Infinity Cache: that ceiling is reported beside the roof.
+VMEM_PEAK_GBS = 256 * 64 * 2.4e9 / 1e9
+VMEM_PER_LANE_PATTERN_GBS = 256 * 16 * 2.4e9 / 1e9
+# Lane-operations the reference's own arithmetic needs, whatever the kernel's instruction count: a step over four boxes is four slab
+# tests (Box.cs:51-79: 6 subtractions, 6 multiplications, 10 min/max = 22 each, unfused) plus 12 to order the survivors (five
+# compare-exchanges and the choice of the nearest); a triangle test is Moeller-Trumbore as Triangle.cs:15-47 writes it: two cross
+# products (18), four dot products (20), a reciprocal, a subtraction of points (3), three scalings and eight comparisons = 53.
+ALG_LANEOPS_PER_STEP = 4 * 22 + 12
+ALG_LANEOPS_PER_TRI = 53
 # Vector-ALU peak, second entry: one wave64 instruction per SIMD every 4 clocks, i.e. 16 lanes per
 # SIMD and clock, 4 SIMDs x 256 CUs at 2.4 GHz.  Not the 157 TFLOP/s headline: that counts packed two-wide FMAs, and this path
 # may neither fuse (bit-exactness with the C# arithmetic) nor pack (one ray per lane).
@@ -119,7 +128,7 @@ def cpu_baseline(name, w, h, bounces, nee, fs, threads):
     cfg = ob.path_config(bounces, nee, 1)
     spp = 4      # of the frame's 16: the same pixels, cameras and seeds as the GPU's first 4 samples
     t0 = time.perf_counter()
-    _, st = o.render(rs, fs, cfg, spp, traversal="literal", threads=threads)
+    osum, st = o.render(rs, fs, cfg, spp, traversal="literal", threads=threads)
     dt = time.perf_counter() - t0
     rays = st["extend_rays"] + st["shadow_rays"]
     stride = 4   # the reference is single-threaded: one thread on every 4th 8x8 pixel group, 1 spp
@@ -127,7 +136,11 @@ def cpu_baseline(name, w, h, bounces, nee, fs, threads):
     _, st1 = o.render(rs, fs, cfg, 1, traversal="literal", threads=1, group_stride=stride)
     dt1 = time.perf_counter() - t1
     rays1 = st1["extend_rays"] + st1["shadow_rays"]
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    # the image for the parity check: the same samples through the oracle's canonical walk (closest hit with ties to the smaller
+    # triangle index — the contract of the GPU path); the literal order may keep another triangle of an exact distance tie
+    csum, _ = o.render(rs, fs, cfg, spp, traversal="canonical", threads=threads)
+    literal_ties = int((csum.view(np.uint32) != osum.view(np.uint32)).any(axis=-1).sum())
+    return csum / np.float32(spp), literal_ties, {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "host_cpu_count": os.cpu_count(),
             "sample": f"{spp} of the frame's samples per pixel, whole image ({rays} rays in {dt:.1f} s on {threads} threads = every CPU this "
                       f"job may use; os.cpu_count() = {os.cpu_count()} is the whole machine); "
@@ -166,8 +179,18 @@ class Run:
         self.spp_total = self.spp if strong else self.spp * world
         scene = build_scene(name, threads=min(16, host_threads()))
         self.mats, self.tris, self.nodes = scene.arrays()
-        self.wf = pa.Wavefront(device=local_rank, nee=bool(nee), rng_mode=1, tile_rank=rank, tile_world=world,
-                               samples_per_batch=args.batch, stage_timing=1)
+        self.n_quads = count_quads(self.nodes)
+        # the library's rule: trees whose exact records exceed the 32 MiB of L2 are walked through the quantised 64-byte records
+        self.quant = self.n_quads * 128 > (32 << 20) if args.quant == 2 else bool(args.quant)
+        self.in_process = getattr(args, "in_process", 0)
+        if self.in_process:
+            # one process, one context over N GPUs: tiles and the RCCL gather are inside the library (pt_config.device_count)
+            self.wf = pa.Wavefront(device=0, nee=bool(nee), rng_mode=1, samples_per_batch=args.batch, stage_timing=1, device_count=self.in_process,
+                                   group_flags=1 if args.same_device else 0)
+            self.spp_total = self.spp if strong else self.spp * self.in_process
+        else:
+            self.wf = pa.Wavefront(device=local_rank, nee=bool(nee), rng_mode=1, tile_rank=rank, tile_world=world,
+                                   samples_per_batch=args.batch, stage_timing=1)
         self.wf.upload_scene(self.mats, self.tris, self.nodes)
         if args.blocks >= 0:
             self.wf.set_option(6, args.blocks)
@@ -175,11 +198,14 @@ class Run:
             self.wf.set_option(7, args.refill_primary)
         if args.refill_bounce:
             self.wf.set_option(8, args.refill_bounce)
+        if args.quant != 2:
+            self.wf.set_option(9, args.quant)
         self.wf.allocate(self.w, self.h)
         self.pos, self.tgt = view_of(name)
         self.cam = Camera(self.w, self.h, None)
         self.fs = self.cam.frame_state(self.pos, self.tgt, frames=1, samples=0)
-        self.gather = tiles.AccumulatorGather(self.wf, dst=0) if world > 1 else None
+        self.gather = tiles.AccumulatorGather(self.wf, dst=0) if (world > 1 and not self.in_process) else None
+        self.image = None
 
     def step(self):
         self.wf.invoke(self.fs, spp=self.spp_total, max_bounces=self.bounces, wait=False)
@@ -187,6 +213,8 @@ class Run:
         self.fs["samples"] += self.spp_total
         if self.gather is not None:
             self.gather()   # the image's tiles to rank 0; RCCL moves them while the next image renders
+        if self.in_process:
+            self.image = self.wf.read_image()   # the library's own gather (grouped ncclSend / ncclRecv) + assembly + read-out, inside the timed region
 
     def instrumented(self):
         """One un-timed step with the counting kernels (BVH steps, triangle tests, wave iterations), one with every stage
@@ -209,7 +237,7 @@ class Run:
         self.wf.close()
 
 
-def traversal_roofline(counted, timed, kernel_cost, n_quads, n_tris, pmc):
+def traversal_roofline(counted, timed, kernel_cost, n_quads, n_tris, pmc, quant=False, gpus=1):
     """The extend kernel against the roof that binds it — the vector memory pipeline's return rate — from counts of the
     instrumented pass and HIP-event times of the timed steps.
 
@@ -226,29 +254,38 @@ def traversal_roofline(counted, timed, kernel_cost, n_quads, n_tris, pmc):
     launches = max(1, timed["extend_launches"])
     avg_ms = timed["ms_extend"] / launches
     sec = max(1e-12, avg_ms * 1e-3)
-    rays_per_launch = timed["extend_rays"] / launches
-    loads_per_ray = 7.0 * usteps_per_ray + 3.0 * utris_per_ray + 2.0
+    rays_per_launch = timed["extend_rays"] / launches / gpus   # a multi-GPU context adds the GPUs' rays up and reports launches per GPU
+    # 16-byte loads per record: exact quad record 7 (112 of 128 bytes), triangle 3; the quantised walk's records are 4 and 4
+    step_loads, tri_loads = (4.0, 4.0) if quant else (7.0, 3.0)
+    loads_per_ray = step_loads * usteps_per_ray + tri_loads * utris_per_ray + 2.0
     vmem_achieved = 16.0 * loads_per_ray * rays_per_launch / sec / 1e9
     laneops_per_ray = steps_per_ray * i_int + tris_per_ray * i_leaf
     valu_achieved = laneops_per_ray * rays_per_launch / sec / 1e12
+    alg_laneops_per_ray = steps_per_ray * ALG_LANEOPS_PER_STEP + tris_per_ray * ALG_LANEOPS_PER_TRI
+    valu_alg_achieved = alg_laneops_per_ray * rays_per_launch / sec / 1e12
     lane_int = counted["extend_steps"] / max(1, 64 * counted["sched_interior"])
     lane_leaf = counted["extend_tris"] / max(1, 64 * counted["sched_leaf"])
     issued = counted["sched_interior"] * i_int + counted["sched_leaf"] * i_leaf     # wave instructions, the two loops only
     # HBM: the bytes a launch cannot avoid moving are its ray records (32 in, 16 out) and one pass over the tree and the hot
     # triangle records; everything else the walk touches is re-use that the caches serve
-    scene_bytes = 128.0 * n_quads + 48.0 * n_tris
+    scene_bytes = (64.0 * n_quads + 64.0 * n_tris) if quant else (128.0 * n_quads + 48.0 * n_tris)
     hbm_alg = 48.0 * rays_per_launch + scene_bytes
     hbm_achieved = hbm_alg / sec / 1e9
-    vmem = {"bound": "vmem", "bound_note": "vector memory pipeline: one lane's 16-byte load returned per clock and CU (tools/micro/ta_rate.hip, "
-                                           "profiles/r02_micro_ta_rate.txt); binds incoherent rays",
+    vmem = {"bound": "vmem", "bound_note": "vector memory: 64 B per clock and CU for wave-coalesced lines (tools/micro/gather_rate.hip, profiles/r03_micro_gather_rate.txt); "
+                                           "the per-lane record fetch of a traversal step is served at a quarter of that (frac_of_per_lane_pattern_ceiling)",
             "achieved": vmem_achieved, "peak": VMEM_PEAK_GBS, "unit": "GB/s", "frac": vmem_achieved / VMEM_PEAK_GBS,
+            "frac_of_per_lane_pattern_ceiling": vmem_achieved / VMEM_PER_LANE_PATTERN_GBS, "per_lane_pattern_ceiling": VMEM_PER_LANE_PATTERN_GBS,
             "bytes_per_launch": 16.0 * loads_per_ray * rays_per_launch, "distinct_16B_loads_per_ray": loads_per_ray,
             "distinct_bvh_records_per_ray": usteps_per_ray, "distinct_tri_records_per_ray": utris_per_ray,
-            "measured_ceilings_gbs": {"source": "profiles/r02_micro_ta_rate.txt", "contiguous": 9700.0, "own_128B_record_L2_resident": 8500.0,
-                                      "own_128B_record_infinity_cache_resident": 6880.0}}
+            "node_records": "quantised, 64 B" if quant else "exact, 128 B",
+            "measured_ceilings_gbs": {"source": "profiles/r03_micro_gather_rate.txt, profiles/r03_micro_coop_fetch.txt", "wave_coalesced_rows_from_L2": 31600.0,
+                                      "per_lane_records_from_L2": 9700.0, "per_lane_records_from_infinity_cache": 7300.0}}
     valu = {"bound": "valu", "bound_note": "vector-ALU issue: one wave64 instruction per SIMD every 4 clocks, unfused and unpacked (bit-exactness with the C# "
                                            "arithmetic forbids FMA contraction); binds coherent rays, whose loads the pipeline serves together",
             "achieved": valu_achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": valu_achieved / VALU_PEAK_TLANEOPS,
+            # the same with the reference arithmetic's own operation counts instead of the kernel's instruction counts
+            "achieved_algorithmic": valu_alg_achieved, "frac_algorithmic": valu_alg_achieved / VALU_PEAK_TLANEOPS,
+            "algorithmic_lane_ops": {"per_4_box_step": ALG_LANEOPS_PER_STEP, "per_triangle_test": ALG_LANEOPS_PER_TRI, "per_ray": alg_laneops_per_ray},
             "valu_instr_per_interior_iteration": i_int, "valu_instr_per_leaf_phase": i_leaf, "lane_ops_per_ray": laneops_per_ray,
             "lane_utilisation": {"interior": lane_int, "leaf": lane_leaf,
                                  "overall": (counted["extend_steps"] * i_int + counted["extend_tris"] * i_leaf) / max(1, 64 * issued)},
@@ -261,6 +298,8 @@ def traversal_roofline(counted, timed, kernel_cost, n_quads, n_tris, pmc):
     # the roof that binds is the one the kernel sits closest to; the other two stay in the line
     first, second = (vmem, valu) if vmem["frac"] >= valu["frac"] else (valu, vmem)
     out = dict(first)
+    out.setdefault("frac_algorithmic", valu["frac_algorithmic"])
+    out.setdefault("lane_utilisation", valu["lane_utilisation"])
     out.update({
         "kernel": "k_extend",
         "traffic": pmc.get("extend_hbm_bytes_per_launch"),
@@ -300,7 +339,11 @@ def secondary_soup(args, cost, steps=3):
     # frames connect of a bounce runs beside extend of the next one, and an extend launch's events then span shared time)
     bounce_rays = staged["extend_rays"] - staged["paths"]
     bounce_ms = staged["ms_extend"] - staged["ms_extend_primary"]
-    roof = traversal_roofline(counted, staged, cost["k_extend"], count_quads(run.nodes), int(run.tris.size), committed_pmc("c3"))
+    kcost = cost["k_extend_quant" if run.quant else "k_extend"]
+    # live: the extend launches of the timed frames (a launch may share the GPU with the previous bounce's connect for part of its
+    # time) — what a kernel trace of this command shows; alone: the frame whose stages ran back to back
+    roof = traversal_roofline(counted, st, kcost, run.n_quads, int(run.tris.size), committed_pmc("c3"), run.quant)
+    alone = traversal_roofline(counted, staged, kcost, run.n_quads, int(run.tris.size), committed_pmc("c3"), run.quant)
     out = {
         "workload": run.desc, "steps": steps, "ms_per_frame": dt / steps * 1e3,
         "mrays_per_s": (st["extend_rays"] + st["shadow_rays"]) / dt / 1e6,
@@ -313,8 +356,11 @@ def secondary_soup(args, cost, steps=3):
         "rays_per_frame": {"extend": st["extend_rays"] / steps, "bounce": bounce_rays, "shadow": st["shadow_rays"] / steps},
         "shadow_bvh_steps_per_ray": counted["shadow_steps"] / max(1, counted["shadow_rays"]),
         "shadow_tri_tests_per_ray": counted["shadow_tris"] / max(1, counted["shadow_rays"]),
-        "roofline": {**{k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "bvh_steps_per_ray", "tri_tests_per_ray")},
-                     "other_roofs": {k: {"frac": v["frac"], "achieved": v["achieved"], "peak": v["peak"], "unit": v["unit"]} for k, v in roof["other_roofs"].items()}},
+        "node_records": "quantised, 64 B" if run.quant else "exact, 128 B",
+        "roofline": {**{k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_algorithmic", "avg_launch_ms", "launches", "rays_per_launch",
+                                                 "bvh_steps_per_ray", "tri_tests_per_ray", "lane_utilisation")},
+                     "other_roofs": {k: {"frac": v["frac"], "achieved": v["achieved"], "peak": v["peak"], "unit": v["unit"]} for k, v in roof["other_roofs"].items()},
+                     "kernel_alone": {k: alone.get(k) for k in ("bound", "achieved", "frac", "frac_algorithmic", "avg_launch_ms")}},
     }
     run.close()
     return out
@@ -351,10 +397,23 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1M-triangle soup block of the N = 1 line")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only for rehearsing N > 1 on a single GPU")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
+    ap.add_argument("--quant", type=int, default=2, choices=[0, 1, 2], help="node records the traversal walks: 0 exact 128-byte, 1 quantised 64-byte, 2 the library's rule")
+    ap.add_argument("--in-process", action="store_true", help="N GPUs behind ONE context in this one process (pt_config.device_count = N: tile sharding and the "
+                    "RCCL gather inside libpt_hip.so) instead of one process per GPU")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if not launched and args.gpus > 1:
+    if args.same_device and args.gpus > 1 and args.backend == "nccl" and not args.in_process:
+        # RCCL refuses two ranks of one communicator on one device (ncclInvalidUsage, "Duplicate GPU detected"), and some versions wait
+        # in the bootstrap instead of returning: say so instead of starting ranks that cannot finish
+        print("bench.py: --same-device with --backend nccl cannot work: RCCL needs one GPU per rank (ncclCommInitRank fails with "
+              "ncclInvalidUsage 'Duplicate GPU detected' when two ranks name one device). Rehearse with --backend gloo, or use --in-process "
+              "--same-device (members of one context share the GPU and move tiles by device copies).", file=sys.stderr, flush=True)
+        return 2
+    args.in_process = args.gpus if args.in_process else 0
+    if args.in_process:
+        launched = False          # one process drives all the GPUs
+    if not launched and args.gpus > 1 and not args.in_process:
         # Start the N ranks ourselves, as fresh child processes, before this process has touched the GPU (it never will).
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -362,10 +421,11 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         return subprocess.run(cmd, env=env).returncode
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    args.gpus = world
+    rank = int(os.environ.get("RANK", "0")) if not args.in_process else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if not args.in_process else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if not args.in_process else 1
+    if not args.in_process:
+        args.gpus = world
 
     import torch
     import torch.distributed as dist
@@ -406,13 +466,14 @@ def main():
 
     if rank == 0:
         cost = isa_cost()
-        roof = traversal_roofline(counted, st, cost["k_extend"], count_quads(run.nodes), int(run.tris.size), committed_pmc(args.workload))
+        kcost = cost["k_extend_quant" if run.quant else "k_extend"]
+        roof = traversal_roofline(counted, st, kcost, run.n_quads, int(run.tris.size), committed_pmc(args.workload), run.quant, args.in_process or 1)
         roof["shadow_bvh_steps_per_ray"] = counted["shadow_steps"] / max(1, counted["shadow_rays"])
         roof["shadow_tri_tests_per_ray"] = counted["shadow_tris"] / max(1, counted["shadow_rays"])
         # in the timed steps connect of a bounce runs beside extend of the next one: an extend launch shares the GPU for part of its
         # time.  The same figures from the frame whose stages ran back to back, the kernel having the GPU to itself:
-        alone = traversal_roofline(counted, staged, cost["k_extend"], count_quads(run.nodes), int(run.tris.size), committed_pmc(args.workload))
-        roof["kernel_alone"] = {k: alone[k] for k in ("bound", "achieved", "frac", "avg_launch_ms", "extend_mrays_per_s")}
+        alone = traversal_roofline(counted, staged, kcost, run.n_quads, int(run.tris.size), committed_pmc(args.workload), run.quant, args.in_process or 1)
+        roof["kernel_alone"] = {k: alone[k] for k in ("bound", "achieved", "frac", "frac_algorithmic", "avg_launch_ms", "extend_mrays_per_s")}
         roof["kernel_alone"]["fracs"] = {alone["bound"]: alone["frac"], **{k: v["frac"] for k, v in alone["other_roofs"].items()}}
         roof["kernel_alone"]["bounce_extend_mrays_per_s"] = ((staged["extend_rays"] - staged["paths"]) /
                                                              max(1e-9, (staged["ms_extend"] - staged["ms_extend_primary"]) * 1e-3) / 1e6)
@@ -423,24 +484,35 @@ def main():
         overridden = args.spp or args.width or args.height or args.bounces
         out = {
             "metric": "Mrays/s (primary+bounce+shadow rays traced)", "value": (extend_rays + shadow_rays) / dt / 1e6, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": args.in_process or world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": run.desc if not overridden else f"{args.workload} {run.w}x{run.h} {run.spp} spp {run.bounces} bounces nee={run.nee}",
                        "width": run.w, "height": run.h, "spp_per_gpu": run.spp, "spp_total": run.spp_total, "max_bounces": run.bounces,
                        "nee": run.nee, "triangles": int(run.tris.size), "nodes": int(run.nodes.size),
-                       "tiles": f"8x8 groups round-robin over {world} rank(s)",
+                       "tiles": (f"8x8 groups round-robin over {args.in_process} GPUs behind one context (pt_config.device_count), gather + read-out inside the timed region"
+                                 if args.in_process else f"8x8 groups round-robin over {world} rank(s)"),
+                       "node_records": "quantised, 64 B" if run.quant else "exact, 128 B",
                        "rays_per_step": (extend_rays + shadow_rays) / args.steps,
                        "extend_rays_per_step": extend_rays / args.steps, "shadow_rays_per_step": shadow_rays / args.steps},
             "roofline": roof,
             "stage_ms_per_step": stage_ms,   # from one un-timed step with every stage bracketed by events
         }
-        run.close()
-        if world == 1 and not args.no_cpu_baseline and args.workload in ("bundled", "c1", "soup1m", "c3"):
+        if world == 1 and not args.in_process and not args.no_cpu_baseline and args.workload in ("bundled", "c1", "soup1m", "c3"):
             fs0 = run.cam.frame_state(run.pos, run.tgt, frames=1, samples=0)
-            out["cpu_baseline"] = cpu_baseline(args.workload, run.w, run.h, run.bounces, run.nee, fs0, host_threads())
+            oimg, literal_ties, out["cpu_baseline"] = cpu_baseline(args.workload, run.w, run.h, run.bounces, run.nee, fs0, host_threads())
+            # the checker at work: the oracle's 4 samples per pixel of the whole frame against the GPU's first 4, bit for bit
+            wf.allocate(run.w, run.h)
+            wf.invoke(fs0, spp=4, max_bounces=run.bounces)
+            gimg = wf.read_image()
+            differing = int((gimg.view(np.uint32) != oimg.view(np.uint32)).any(axis=-1).sum())
+            out["cpu_baseline"]["parity_checked"] = differing == 0
+            out["cpu_baseline"]["parity_note"] = (f"{differing} of {run.w * run.h} pixels of the GPU's first 4 samples per pixel differ bitwise from the oracle's image "
+                                                  f"of the same samples; the literal C# visiting order, which is what the baseline times, gives {literal_ties} pixels "
+                                                  "another triangle of an exact distance tie")
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not args.no_secondary and args.workload == "bundled" and not overridden:
+        run.close()
+        if world == 1 and not args.in_process and not args.no_secondary and args.workload == "bundled" and not overridden:
             out["secondary"] = secondary_soup(args, cost)
         print(json.dumps(out), flush=True)
     else:
