@@ -19,7 +19,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def counters(path, kernel="void k_extend<false>"):
+def counters(path, kernel="void k_extend<false, false>"):
     vals = {}
     for line in open(path):
         m = re.match(re.escape(kernel) + r"\s+(\S+)\s+mean/dispatch\s+([\d.]+)", line)
@@ -34,13 +34,13 @@ def traffic_entry(vals, source, command):
     simd_cycles = 1024 * vals["GRBM_GUI_ACTIVE"] / 8
     return {
         "extend_hbm_bytes_per_launch": rd + wr, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
-        "method": "rocprofv3 --pmc, separate passes: TCC_EA0_RDREQ{,_32B,_64B,_128B}_sum and TCC_EA0_WRREQ{,_64B}_sum of k_extend<false>, mean per dispatch; "
+        "method": "rocprofv3 --pmc, separate passes: TCC_EA0_RDREQ{,_32B,_64B,_128B}_sum and TCC_EA0_WRREQ{,_64B}_sum of the timed k_extend instantiation (no counting; exact or quantised records as the scene takes), mean per dispatch; "
                   "read bytes = 128*n128 + 64*n64 + 32*n32, write bytes = 64*n64 + 32*(n - n64) (FETCH_SIZE tallies 128-B requests as 64 B on gfx950; the "
                   "request-size breakdown is the figure used). L2 memory-side requests: Infinity-Cache hits are included, so this is an upper bound on HBM bytes.",
         "tcc_hit_rate": vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]),
         "valu_busy": vals["SQ_INSTS_VALU"] * 4 / simd_cycles,
         "sq_insts_valu_per_launch": vals["SQ_INSTS_VALU"],
-        "valu_busy_method": "SQ_INSTS_VALU (wave instructions, 4 cycles each on a 16-lane SIMD) over 1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs, k_extend<false>, mean per dispatch",
+        "valu_busy_method": "SQ_INSTS_VALU (wave instructions, 4 cycles each on a 16-lane SIMD) over 1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs, the timed k_extend instantiation, mean per dispatch",
         "waves_per_simd": 4 * vals["SQ_WAVE_CYCLES"] / simd_cycles,
         "waves_per_simd_method": "4 x SQ_WAVE_CYCLES over SIMD clocks: resident waves per SIMD averaged over the launch.  SQ_WAVE_CYCLES is taken to count in units "
                                  "of 4 clocks here (the raw quotient is 1.3-1.4 for launches whose grid places exactly 6 waves on every SIMD and keeps them until "
@@ -58,7 +58,9 @@ def main():
     for w, args in (("bundled", ""), ("c3", " --workload c3 --steps 1")):
         summary = os.path.join(out, f"{run}_pmc_{w}_summary.txt")
         shutil.copy(summary, os.path.join(prof, f"{tag}_bench_{w}_pmc.txt"))
-        traffic[w] = traffic_entry(counters(summary), f"profiles/{tag}_bench_{w}_pmc.txt", "python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-secondary" + args)
+        # the headline scene is walked through the exact records, the soup (a tree beyond L2) through the quantised ones
+        kernel = "void k_extend<false, true>" if w == "c3" else "void k_extend<false, false>"
+        traffic[w] = traffic_entry(counters(summary, kernel), f"profiles/{tag}_bench_{w}_pmc.txt", "python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-secondary" + args)
         stats = sorted(glob.glob(os.path.join(out, f"{run}_pmc_{w}", "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
         shutil.copy(stats[-1], os.path.join(prof, f"{tag}_bench_{w}_kernel_stats.csv"))
     json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)

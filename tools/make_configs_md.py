@@ -14,7 +14,7 @@ def main():
     print("# Every BASELINE.json configuration on one MI355X\n")
     print("`python bench.py --workload <name> --steps 3 --warmup 1` (this table: `tools/make_configs_md.py`), one GPU, scene and queues resident in HBM.")
     print("c4 and c5 use synthetic stand-ins of the named triangle counts; their lines are the single-GPU leg of the 8-GPU configurations (every rank holds")
-    print("the whole scene and traces its own tiles).  Roofs: vmem = vector-memory return rate (9,830 GB/s of distinct 16-byte loads), valu = vector-ALU issue")
+    print("the whole scene and traces its own tiles).  Roofs: vmem = vector-memory return rate for wave-coalesced lines (39,322 GB/s nominal; the per-lane record fetch of a traversal step is served at a quarter of it), valu = vector-ALU issue")
     print("(39.3 T lane-op/s), hbm = 8,000 GB/s; the bound named is the roof the extend kernel sits closest to.\n")
     print("The timed frames run connect of a bounce beside extend of the next one, so an extend launch shares the GPU for part of its time: the")
     print("extend columns and the roof fractions are those of the frame whose stages ran back to back (the kernel alone); `live frac` is the")
