@@ -191,6 +191,29 @@ int pt_build_bvh(pt_ctx* ctx, const void* triangles_in, int32_t n_tri, void* tri
 int pt_build_scene(pt_ctx* ctx, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri, void* triangles_out,
                    void* nodes_out, int32_t node_capacity, int32_t* n_nodes, float* build_ms);
 
+/* pt_build_scene for a scene made of meshes placed by matrices, with a second acceleration structure over the instances (no
+ * counterpart in the reference, whose Scene.AddMesh flattens every mesh into world-space triangles, PathTracer/Scene.cs:122-174).
+ * The flattened scene is built and installed exactly as by pt_build_scene — triangle ids in results, materials, normals and the
+ * default traversal are its — and beside it a tree over the instances' world boxes plus one tree per mesh in the mesh's own space
+ * (a 20M-triangle scene of 4,026 bunnies walks 0.7 MB of records instead of 1.6 GB).  pt_set_option(PT_OPT_INSTANCED, 1) makes
+ * the traversal kernels walk that structure.  Triangles are still tested in world space on vertices re-derived from the mesh
+ * vertex and the instance matrix, which must reproduce the flattened triangle bit for bit (checked: PT_E_INVALID_ARG otherwise),
+ * so a hit's distance and barycentrics are the flattened walk's; what differs is eligibility: the flattened walk, like the
+ * reference, drops a hit whose leaf box the ray misses by rounding, this walk does not, and exact distance ties go to the triangle
+ * listed first rather than to the smaller built index.
+ * triangles_in: the flattened list in Accelerator.AddTriangle order.  mesh_triangles: every mesh's triangles in its own space,
+ * mesh m at [mesh_first[m], mesh_first[m] + mesh_count[m]).  instances: in any order, together tiling triangles_in — instance i
+ * owns the mesh_count[mesh] triangles from first_triangle on, triangle k of them being mesh triangle k under
+ * System.Numerics.Vector3.Transform(vertex, transform) (PathTracer/Library/Geometry/Mesh.cs:50-70). */
+typedef struct pt_instance {
+    float transform[16];        /* Matrix4x4 M11..M44 row by row, row-vector convention (translation in M41..M43) */
+    int32_t mesh;
+    int32_t first_triangle;
+} pt_instance;
+int pt_build_scene_instanced(pt_ctx* ctx, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri,
+                             const void* mesh_triangles, const int32_t* mesh_first, const int32_t* mesh_count, int32_t n_meshes,
+                             const pt_instance* instances, int32_t n_instances, float* build_ms);
+
 /* Runtime switches: key is one of PT_OPT_*; takes effect at the next pt_render. */
 enum { PT_OPT_NEE = 1, PT_OPT_RNG_MODE = 2, PT_OPT_TRAVERSAL_STATS = 3, PT_OPT_STAGE_TIMING = 4, PT_OPT_SAMPLES_PER_BATCH = 5,
        PT_OPT_TRAVERSE_BLOCKS_PER_CU = 6 /* resident 256-thread blocks per CU of the traversal kernels; 0 = the default (at most 7) */,
@@ -198,7 +221,9 @@ enum { PT_OPT_NEE = 1, PT_OPT_RNG_MODE = 2, PT_OPT_TRAVERSAL_STATS = 3, PT_OPT_S
        PT_OPT_REFILL_BOUNCE = 8 /* the same for bounce and shadow rays; default 40 */,
        PT_OPT_QUANTIZED = 9 /* which node records the traversal kernels walk: 0 the exact 128-byte records, 1 the 64-byte records
                                with boxes on a 16-bit grid (the exact leaf boxes are then applied at the triangles: hits are the
-                               same), 2 (default) the 64-byte records for trees that exceed the L2 caches */ };
+                               same), 2 (default) the 64-byte records for trees that exceed the L2 caches */,
+       PT_OPT_INSTANCED = 10 /* 1: walk the instances of a scene installed by pt_build_scene_instanced (0, the default, and every
+                                scene installed another way: the flattened triangles) */ };
 int pt_set_option(pt_ctx* ctx, int32_t key, int32_t value);
 
 /* ---- multi-GPU tiles, one process per GPU --------------------------------------

@@ -77,6 +77,16 @@ int pth_scene_arrays(pth_scene* s, const void** materials48, const void** triang
  * Valid until the scene changes. */
 int pth_scene_references(pth_scene* s, const void** triangles112, const void** materials48, int32_t* n_triangles, int32_t* n_materials);
 
+/* The scene as meshes and instances, for pt_build_scene_instanced (no reference counterpart: Scene.AddMesh flattens every mesh into
+ * world-space triangles, PathTracer/Scene.cs:122-174).  Every pth_scene_add_mesh call (and every object of the scene recipes) is an
+ * instance of the mesh (name, normalized) under its matrix; runs of triangles that did not come from a mesh become meshes of their own,
+ * instanced once under the identity.  Every triangle of pth_scene_references belongs to exactly one instance, in order, and
+ * Vector3.Transform(object-space vertex, instance matrix) reproduces its vertices bit for bit.
+ * Call with null arrays for the three counts, then with arrays of those sizes: mesh_triangles112 (object space, 112 B each),
+ * mesh_first / mesh_count (one per mesh: its range in mesh_triangles112), instances72 (pt_instance records of pt_hip.h). */
+int pth_scene_instancing(pth_scene* s, int32_t* n_meshes, int32_t* n_mesh_triangles, int32_t* n_instances, void* mesh_triangles112,
+                         int32_t* mesh_first, int32_t* mesh_count, void* instances72);
+
 /* Camera.Update, PathTracer/Camera.cs:46-61, in two halves around the autofocus ray of
  * Camera.GetFocalDistance (Camera.cs:89-95), which the caller traces with pt_trace_closest:
  * pth_camera_basis gives forward/right/up; pth_camera_state takes the hit distance of the ray

@@ -46,7 +46,7 @@ PT_HIP_SYMBOLS = ["pt_default_config", "pt_create", "pt_destroy", "pt_last_error
                   "pt_set_render_state", "pt_reset_accumulation", "pt_render", "pt_synchronize", "pt_read_image",
                   "pt_trace_closest", "pt_trace_occluded", "pt_generate_rays", "pt_get_stats", "pt_reset_stats",
                   "pt_set_option", "pt_bench_extend", "pt_accum_device", "pt_assemble_tiles", "pt_stream", "pt_build_bvh", "pt_build_scene",
-                  "pt_trace_closest_noalloc"]
+                  "pt_trace_closest_noalloc", "pt_build_scene_instanced"]
 
 _hip = None
 _host = None
@@ -94,6 +94,7 @@ def hip():
         lib.pt_bench_extend.argtypes = [vp, vp, i32, i32, C.POINTER(C.c_float), vp, vp]
         lib.pt_build_bvh.argtypes = [vp, vp, i32, vp, vp, i32, C.POINTER(i32), C.POINTER(C.c_float)]
         lib.pt_build_scene.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, C.POINTER(i32), C.POINTER(C.c_float)]
+        lib.pt_build_scene_instanced.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, C.POINTER(C.c_float)]
         lib.pt_get_stats.argtypes = [vp, C.POINTER(pt_stats)]
         lib.pt_reset_stats.argtypes = [vp]
         lib.pt_set_option.argtypes = [vp, i32, i32]

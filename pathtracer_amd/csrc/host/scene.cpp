@@ -302,6 +302,14 @@ struct pth_scene {
     Accelerator accelerator;
     std::map<std::string, MeshData> cache;
 
+    // What the scene is made of, for a host that wants the GPU to walk instances instead of the flattened triangles: every
+    // addMesh call is one instance of the mesh (name, normalized) under its matrix.  The reference has no such notion
+    // (Scene.AddMesh flattens, Scene.cs:122-174); nothing here changes what AddTriangle receives.
+    struct MeshRef { std::string name; bool normalized; };
+    struct InstanceRef { int mesh; int first; int count; Mat4 transform; };
+    std::vector<MeshRef> meshRefs;
+    std::vector<InstanceRef> instanceRefs;
+
     const MeshData& mesh(const std::string& name) {
         auto it = cache.find(name);
         if (it != cache.end()) return it->second;
@@ -317,7 +325,8 @@ struct pth_scene {
     }
 
     // Scene.LoadGroup + Face.Triangulate + Mesh.GetPosition/GetNormal (Scene.cs:159-174, Face.cs:23-65, Mesh.cs:50-70)
-    void addGroup(const MeshData& mesh, const MeshGroup& group, bool normalized, const Mat4& transform, int material) {
+    // sink: where the triangles go instead of the accelerator (the object-space copy of a mesh for instancing)
+    void addGroup(const MeshData& mesh, const MeshGroup& group, bool normalized, const Mat4& transform, int material, std::vector<Triangle>* sink = nullptr) {
         const Vec3 extent = sub(mesh.hi, mesh.lo);
         const float largest = maxNaN(maxNaN(extent.x, extent.y), extent.z);
         auto corner = [&](const Corner& c) {
@@ -341,7 +350,8 @@ struct pth_scene {
                     const Vec3 flat = normalize(cross(sub(a.Position, c.Position), sub(b.Position, c.Position)));
                     a.Normal = b.Normal = c.Normal = flat;
                 }
-                accelerator.AddTriangle(triangleOf(a, b, c, material));
+                if (sink) sink->push_back(triangleOf(a, b, c, material));
+                else accelerator.AddTriangle(triangleOf(a, b, c, material));
                 b = c;
             }
         }
@@ -349,6 +359,14 @@ struct pth_scene {
 
     void addMesh(const std::string& name, bool normalized, const Mat4& transform, const Material* material) {
         const MeshData& m = mesh(name);
+        int ref = -1;
+        for (size_t i = 0; i < meshRefs.size(); i++) if (meshRefs[i].name == name && meshRefs[i].normalized == normalized) ref = (int)i;
+        if (ref < 0) { meshRefs.push_back({name, normalized}); ref = (int)meshRefs.size() - 1; }
+        const int firstTriangle = accelerator.Count();
+        struct Note {   // records the instance once its triangles are in, on every way out
+            pth_scene* s; int ref, first; Mat4 t;
+            ~Note() { s->instanceRefs.push_back({ref, first, s->accelerator.Count() - first, t}); }
+        } note{this, ref, firstTriangle, transform};
         if (material) {
             const int id = materialIndex(*material);
             for (const auto& g : m.groups) addGroup(m, g, normalized, transform, id);
@@ -420,6 +438,56 @@ struct pth_scene {
     // Synthetic many-instance scene (no reference counterpart; the reference has no instancing, so
     // instances are flattened): `count` bunnies on a cubic grid of pitch 2.5 with random rotations,
     // scales in [0.8, 1.8) and materials drawn like the bundled recipe's, plus the light and a floor.
+    // The scene as meshes and instances: every triangle of the flattened array belongs to exactly one instance, in order.
+    // A mesh's triangles are what addMesh would insert under the identity matrix (Vector3.Transform by the identity returns its
+    // argument bit for bit), so Transform(object vertex, instance matrix) reproduces the flattened vertex exactly.  Triangles that
+    // did not come from addMesh (the tiled floor, a soup, AddTriangle calls) form runs that become meshes of their own, instanced once
+    // under the identity.
+    struct Instancing {
+        std::vector<Triangle> meshTriangles;
+        std::vector<int32_t> meshFirst, meshCount;
+        struct Inst { float transform[16]; int32_t mesh, first; };
+        std::vector<Inst> instances;
+    };
+    Instancing instancing() {
+        Instancing out;
+        std::vector<int> meshSlot(meshRefs.size(), -1);
+        const std::vector<Triangle>& flat = accelerator.References();
+        auto addLoose = [&](int first, int count) {
+            out.meshFirst.push_back((int32_t)out.meshTriangles.size());
+            out.meshCount.push_back(count);
+            out.meshTriangles.insert(out.meshTriangles.end(), flat.begin() + first, flat.begin() + first + count);
+            Instancing::Inst in;
+            const Mat4 id = identity();
+            std::memcpy(in.transform, id.m, 64);
+            in.mesh = (int32_t)out.meshFirst.size() - 1;
+            in.first = first;
+            out.instances.push_back(in);
+        };
+        int cursor = 0;
+        for (const InstanceRef& r : instanceRefs) {
+            if (r.count == 0) continue;
+            if (r.first < cursor || r.first + r.count > (int)flat.size()) throw std::runtime_error("the scene's instance records do not match its triangles (cleared or loaded since?)");
+            if (r.first > cursor) addLoose(cursor, r.first - cursor);
+            if (meshSlot[r.mesh] < 0) {
+                const MeshData& m = mesh(meshRefs[r.mesh].name);
+                out.meshFirst.push_back((int32_t)out.meshTriangles.size());
+                for (const auto& g : m.groups) addGroup(m, g, meshRefs[r.mesh].normalized, identity(), 0, &out.meshTriangles);
+                out.meshCount.push_back((int32_t)out.meshTriangles.size() - out.meshFirst.back());
+                meshSlot[r.mesh] = (int)out.meshFirst.size() - 1;
+            }
+            if (out.meshCount[meshSlot[r.mesh]] != r.count) throw std::runtime_error("an instance's triangle count differs from its mesh's");
+            Instancing::Inst in;
+            std::memcpy(in.transform, r.transform.m, 64);
+            in.mesh = meshSlot[r.mesh];
+            in.first = r.first;
+            out.instances.push_back(in);
+            cursor = r.first + r.count;
+        }
+        if (cursor < (int)flat.size()) addLoose(cursor, (int)flat.size() - cursor);
+        return out;
+    }
+
     void instancedBunnies(int count, int seed) {
         addMesh("light", false, identity(), nullptr);
         NetRandom rng(seed);
@@ -650,7 +718,7 @@ pth_scene* pth_scene_create(const char* mesh_source) {
 }
 void pth_scene_destroy(pth_scene* s) { delete s; }
 
-int pth_scene_clear(pth_scene* s) { PTH_GUARD(s->materials.clear(); s->accelerator.Clear()) }
+int pth_scene_clear(pth_scene* s) { PTH_GUARD(s->materials.clear(); s->accelerator.Clear(); s->meshRefs.clear(); s->instanceRefs.clear()) }
 
 int pth_scene_add_mesh(pth_scene* s, const char* name, int normalized, const float* matrix16, const void* material48) {
     PTH_GUARD(
@@ -746,6 +814,8 @@ int pth_scene_load(pth_scene* s, const char* path) {
         }
         s->materials.swap(m);
         s->accelerator.Clear();
+        s->meshRefs.clear();
+        s->instanceRefs.clear();
         for (const Triangle& tri : t) s->accelerator.AddTriangle(tri);   // insertion order := built order (a rebuild keeps working)
         s->accelerator.triangles.swap(t);
         s->accelerator.nodes.swap(n))
@@ -765,6 +835,23 @@ int pth_scene_references(pth_scene* s, const void** triangles112, const void** m
     PTH_GUARD(const std::vector<Triangle>& r = s->accelerator.References();
               if (triangles112) *triangles112 = r.data(); if (materials48) *materials48 = s->materials.data();
               if (n_triangles) *n_triangles = (int32_t)r.size(); if (n_materials) *n_materials = (int32_t)s->materials.size())
+}
+
+// The scene as meshes + instances (see pth_scene::instancing).  Call with null arrays for the counts, then with arrays of those sizes:
+// mesh_triangles112 n_mesh_triangles x 112 B (object space), mesh_first / mesh_count n_meshes each, instances72 n_instances x
+// {float transform[16]; int32 mesh; int32 first_triangle} — the layout of pt_instance.
+int pth_scene_instancing(pth_scene* s, int32_t* n_meshes, int32_t* n_mesh_triangles, int32_t* n_instances, void* mesh_triangles112, int32_t* mesh_first,
+                         int32_t* mesh_count, void* instances72) {
+    PTH_GUARD(
+        const pth_scene::Instancing in = s->instancing();
+        static_assert(sizeof(pth_scene::Instancing::Inst) == 72, "pt_instance layout");
+        if (n_meshes) *n_meshes = (int32_t)in.meshFirst.size();
+        if (n_mesh_triangles) *n_mesh_triangles = (int32_t)in.meshTriangles.size();
+        if (n_instances) *n_instances = (int32_t)in.instances.size();
+        if (mesh_triangles112) std::memcpy(mesh_triangles112, in.meshTriangles.data(), in.meshTriangles.size() * sizeof(Triangle));
+        if (mesh_first) std::memcpy(mesh_first, in.meshFirst.data(), in.meshFirst.size() * 4);
+        if (mesh_count) std::memcpy(mesh_count, in.meshCount.data(), in.meshCount.size() * 4);
+        if (instances72) std::memcpy(instances72, in.instances.data(), in.instances.size() * 72))
 }
 
 // Camera.Update first half, Camera.cs:48-50

@@ -6,6 +6,7 @@
 #include "pt_kernels.hpp"
 #include "pt_build.hpp"
 #include "pt_repack.hpp"
+#include "pt_instances.hpp"
 #include <string>
 #include <vector>
 #include <cstring>
@@ -107,6 +108,11 @@ struct pt_ctx {
     // 1 whenever the records exist, 2 for large trees (PT_OPT_QUANTIZED).
     bool quant_ok = false;
     int quant_mode = 2;
+    // The scene as instances of meshes (pt_build_scene_instanced): walked only when the host asks (PT_OPT_INSTANCED), because hits
+    // the flattened walk drops for missing their leaf's box are found by this one.
+    bool inst_ok = false;
+    int inst_mode = 0, fit_inst = 4;
+    void *d_iquads = nullptr, *d_ibig = nullptr, *d_itris = nullptr, *d_iinst = nullptr, *d_built_of = nullptr;
     uint64_t local_pixels = 0;
     int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
     void* scratch_dev = nullptr;   // this device's copy of the fixed staging array (pt_trace_closest_noalloc)
@@ -128,10 +134,12 @@ void freeQueues(pt_ctx* c) {
 }
 
 void freeScene(pt_ctx* c) {
-    void** ps[] = {&c->d_pairs, &c->d_quads, &c->d_big, &c->d_hot, &c->d_cold, &c->d_mats, &c->d_lights, &c->d_qquads, &c->d_gate};
+    void** ps[] = {&c->d_pairs, &c->d_quads, &c->d_big, &c->d_hot, &c->d_cold, &c->d_mats, &c->d_lights, &c->d_qquads, &c->d_gate,
+                   &c->d_iquads, &c->d_ibig, &c->d_itris, &c->d_iinst, &c->d_built_of};
     for (void** p : ps) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
     c->has_scene = false;
     c->quant_ok = false;
+    c->inst_ok = false;
     c->sc = DevScene{};
 }
 
@@ -466,15 +474,17 @@ static int impl_create_single(const pt_config* cfg, pt_ctx** out) {
     }
     c->num_cu = prop.multiProcessorCount;
     int perCu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_extend<false, false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_extend<false, PT_WALK_EXACT>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
     int perCuQ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuQ, k_extend<false, true>, PT_BLOCK, 0) != hipSuccess || perCuQ < 1) perCuQ = 4;
-    perCu = std::min(perCu, perCuQ);   // one grid size for both forms of the kernel
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuQ, k_extend<false, PT_WALK_QUANT>, PT_BLOCK, 0) != hipSuccess || perCuQ < 1) perCuQ = 4;
+    perCu = std::min(perCu, perCuQ);   // one grid size for all forms of the kernel
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuQ, k_extend<false, PT_WALK_INST>, PT_BLOCK, 0) != hipSuccess || perCuQ < 1) perCuQ = 4;
+    c->fit_inst = perCuQ;
     c->fit_extend = perCu;
     perCu = std::min(perCu, 7);   // more resident waves than this thrash the caches on incoherent rays
     c->grid_extend = c->num_cu * perCu;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_connect<false, false>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuQ, k_connect<false, true>, PT_BLOCK, 0) != hipSuccess || perCuQ < 1) perCuQ = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_connect<false, PT_WALK_EXACT>, PT_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuQ, k_connect<false, PT_WALK_QUANT>, PT_BLOCK, 0) != hipSuccess || perCuQ < 1) perCuQ = 4;
     perCu = std::min(perCu, perCuQ);
     c->fit_connect = perCu;
     perCu = std::min(perCu, 7);
@@ -527,6 +537,7 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
         case PT_OPT_REFILL_PRIMARY: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_primary = value; c->refill_primary_set = true; break;
         case PT_OPT_REFILL_BOUNCE: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_bounce = value; c->refill_bounce_set = true; break;
         case PT_OPT_QUANTIZED: if (value < 0 || value > 2) FAIL(c, PT_E_INVALID_ARG, "quantized %d", value); c->quant_mode = value; break;
+        case PT_OPT_INSTANCED: if (value != 0 && value != 1) FAIL(c, PT_E_INVALID_ARG, "instanced %d", value); c->inst_mode = value; break;
         case PT_OPT_SAMPLES_PER_BATCH: if (value < 0) FAIL(c, PT_E_INVALID_ARG, "samples_per_batch %d", value); c->cfg.samples_per_batch = value; break;
         default: FAIL(c, PT_E_INVALID_ARG, "unknown option %d", key);
     }
@@ -611,40 +622,40 @@ int pt_reset_accumulation(pt_ctx* c) {
 // whether the traversal kernels walk the quantised records of the installed scene
 static bool useQuant(const pt_ctx* c) { return c->quant_ok && (c->quant_mode == 1 || (c->quant_mode == 2 && c->large_tree)); }
 
+// which records the traversal kernels walk for the installed scene
+static int walkMode(const pt_ctx* c) {
+    if (c->inst_ok && c->inst_mode) return PT_WALK_INST;
+    return useQuant(c) ? PT_WALK_QUANT : PT_WALK_EXACT;
+}
 // Idle lanes a wave collects before it fetches bounce or shadow rays.  Over the quantised records a step costs the memory pipeline
 // four loads instead of seven, and waves that refill at 24 idle lanes (16 to 32 measure alike) are 5 % faster than at 40.
-static uint32_t bounceRefill(const pt_ctx* c) { return (uint32_t)((useQuant(c) && !c->refill_bounce_set) ? 24 : c->refill_bounce); }
+static uint32_t bounceRefill(const pt_ctx* c) { return (uint32_t)((walkMode(c) == PT_WALK_QUANT && !c->refill_bounce_set) ? 24 : c->refill_bounce); }
+// whether the scene counts as a tree beyond L2 for the queue order and the camera rays' refill threshold (walked as instances it does not)
+static bool largeWalk(const pt_ctx* c) { return c->large_tree && walkMode(c) != PT_WALK_INST; }
+#define PT_LAUNCH_WALK(KERNEL, FLAG, MODE, GRID, BLOCK, STREAM, ...)                                                   \
+    do {                                                                                                                \
+        if ((MODE) == PT_WALK_INST) {                                                                                   \
+            if (FLAG) hipLaunchKernelGGL((KERNEL<true, PT_WALK_INST>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);            \
+            else hipLaunchKernelGGL((KERNEL<false, PT_WALK_INST>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);                \
+        } else if ((MODE) == PT_WALK_QUANT) {                                                                           \
+            if (FLAG) hipLaunchKernelGGL((KERNEL<true, PT_WALK_QUANT>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);           \
+            else hipLaunchKernelGGL((KERNEL<false, PT_WALK_QUANT>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);               \
+        } else {                                                                                                        \
+            if (FLAG) hipLaunchKernelGGL((KERNEL<true, PT_WALK_EXACT>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);           \
+            else hipLaunchKernelGGL((KERNEL<false, PT_WALK_EXACT>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);               \
+        }                                                                                                               \
+    } while (0)
 
+// the persistent grids fill the chip: as many blocks as fit (the instanced kernels need more registers, fewer fit)
+static int traverseGrid(const pt_ctx* c, int grid) { return walkMode(c) == PT_WALK_INST ? std::min(grid, c->num_cu * c->fit_inst) : grid; }
 static void launchExtend(pt_ctx* c, bool stats, int cur, uint32_t refillMin) {
-    const dim3 grid(c->grid_extend), block(PT_BLOCK);
-    if (useQuant(c)) {
-        if (stats) hipLaunchKernelGGL((k_extend<true, true>), grid, block, 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
-        else hipLaunchKernelGGL((k_extend<false, true>), grid, block, 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
-    } else {
-        if (stats) hipLaunchKernelGGL((k_extend<true, false>), grid, block, 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
-        else hipLaunchKernelGGL((k_extend<false, false>), grid, block, 0, c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
-    }
+    PT_LAUNCH_WALK(k_extend, stats, walkMode(c), dim3(traverseGrid(c, c->grid_extend)), dim3(PT_BLOCK), c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
 }
 static void launchConnect(pt_ctx* c, bool stats, int cur, hipStream_t on) {
-    const dim3 grid(c->grid_connect), block(PT_BLOCK);
-    const uint32_t refillMin = bounceRefill(c);
-    if (useQuant(c)) {
-        if (stats) hipLaunchKernelGGL((k_connect<true, true>), grid, block, 0, on, c->sc, c->q, c->d_ctl, cur, refillMin);
-        else hipLaunchKernelGGL((k_connect<false, true>), grid, block, 0, on, c->sc, c->q, c->d_ctl, cur, refillMin);
-    } else {
-        if (stats) hipLaunchKernelGGL((k_connect<true, false>), grid, block, 0, on, c->sc, c->q, c->d_ctl, cur, refillMin);
-        else hipLaunchKernelGGL((k_connect<false, false>), grid, block, 0, on, c->sc, c->q, c->d_ctl, cur, refillMin);
-    }
+    PT_LAUNCH_WALK(k_connect, stats, walkMode(c), dim3(traverseGrid(c, c->grid_connect)), dim3(PT_BLOCK), on, c->sc, c->q, c->d_ctl, cur, bounceRefill(c));
 }
 static void launchTrace(pt_ctx* c, bool anyhit, const TraceSource& src, int n) {
-    const dim3 grid(launchGrid((uint32_t)n)), block(PT_BLOCK);
-    if (useQuant(c)) {
-        if (anyhit) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, c->stream, c->sc, src, n, c->d_ctl);
-        else hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, c->stream, c->sc, src, n, c->d_ctl);
-    } else {
-        if (anyhit) hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, c->stream, c->sc, src, n, c->d_ctl);
-        else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, c->stream, c->sc, src, n, c->d_ctl);
-    }
+    PT_LAUNCH_WALK(k_trace, anyhit, walkMode(c), dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), c->stream, c->sc, src, n, c->d_ctl);
 }
 
 static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32_t max_bounces, bool generate_only) {
@@ -678,7 +689,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
         const bool dense = (c->width % 8 == 0) && (c->height % 8 == 0);
         // dense batches: every slot is a path, and shade of bounce 0 stores each path's first value itself
         rp.plane_fresh = (dense && !generate_only) ? 1 : 0;
-        rp.group_major = (!generate_only && c->large_tree) ? 1 : 0;
+        rp.group_major = (!generate_only && largeWalk(c)) ? 1 : 0;
         if (!rp.plane_fresh) HIPCHECK(c, hipMemsetAsync(c->q.plane, 0, (size_t)total * sizeof(float4), c->stream));
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, dense ? total : 0u, 0ull);
         {
@@ -704,7 +715,7 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
             rp.last_bounce = (b == max_bounces - 1) ? 1 : 0;
             {
                 StageTimer t(c, b == 0 ? 4 : 1);
-                launchExtend(c, stats, cur, (uint32_t)(b == 0 ? ((c->large_tree && !c->refill_primary_set) ? 32 : c->refill_primary) : bounceRefill(c)));
+                launchExtend(c, stats, cur, (uint32_t)(b == 0 ? ((largeWalk(c) && !c->refill_primary_set) ? 32 : c->refill_primary) : bounceRefill(c)));
                 c->host_stats.extend_launches++;
             }
             if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_connected, 0)); connectPending = false; }
@@ -1084,6 +1095,11 @@ struct SceneWork {
     size_t tmpBytes = 0;
     void *pairs = nullptr, *quads = nullptr, *big = nullptr, *hot = nullptr, *cold = nullptr, *mats = nullptr, *lights = nullptr;   // the new scene
     void *qquads = nullptr, *gate = nullptr;
+    void *iquads = nullptr, *ibig = nullptr, *itris = nullptr, *iinst = nullptr, *built_of = nullptr;   // the scene as instances (optional)
+    bool instanced = false;
+    uint32_t itopEntry = 0;
+    float itopMin[3] = {0, 0, 0}, itopMax[3] = {0, 0, 0}, instReach[3] = {-1, -1, -1};
+    std::vector<void*> scratch;   // device buffers of the instanced build, released with this object
     uint32_t* d_qbad = nullptr;
     uint32_t qbad = 0;         // a box that does not fit the grid (non-finite): the scene keeps to the exact records
     hipEvent_t ea = nullptr, eb = nullptr;
@@ -1098,8 +1114,9 @@ struct SceneWork {
     ~SceneWork() {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         void* all[] = {d_in, d_sorted, d_nodes, bn, d_flagA, d_idxA, d_flagB, d_idxB, d_bad, d_parent, d_refs, d_anc[0], d_anc[1], d_dep[0], d_dep[1], d_check, tmp,
-                       pairs, quads, big, hot, cold, mats, lights, qquads, gate, d_qbad};
+                       pairs, quads, big, hot, cold, mats, lights, qquads, gate, d_qbad, iquads, ibig, itris, iinst, built_of};
         for (void* p : all) if (p) (void)hipFree(p);
+        for (void* p : scratch) if (p) (void)hipFree(p);
         if (ea) c->pool.push_back(ea);
         if (eb) c->pool.push_back(eb);
     }
@@ -1182,6 +1199,8 @@ static void adoptScene(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn) {
     freeScene(c);
     c->d_pairs = w.pairs; c->d_quads = w.quads; c->d_big = w.big; c->d_hot = w.hot; c->d_cold = w.cold; c->d_mats = w.mats; c->d_lights = w.lights;
     c->d_qquads = w.qquads; c->d_gate = w.gate;
+    c->d_iquads = w.iquads; c->d_ibig = w.ibig; c->d_itris = w.itris; c->d_iinst = w.iinst; c->d_built_of = w.built_of;
+    w.iquads = w.ibig = w.itris = w.iinst = w.built_of = nullptr;
     w.pairs = w.quads = w.big = w.hot = w.cold = w.mats = w.lights = w.qquads = w.gate = nullptr;
     DevScene& sc = c->sc;
     sc.pairs = (const float4*)c->d_pairs;
@@ -1205,11 +1224,180 @@ static void adoptScene(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn) {
     ptrepack::gridOf(w.root.mn, w.root.mx, &grid);   // the expression k_qrecords evaluated on the device
     for (int k = 0; k < 3; k++) { sc.grid_min[k] = grid.mn[k]; sc.grid_cell[k] = grid.cell[k]; sc.grid_mid[k] = grid.mid[k]; sc.grid_reach[k] = grid.reach[k]; }
     c->quant_ok = n > 0 && w.qbad == 0 && (w.nQuads == 0 || c->d_qquads != nullptr) && c->d_gate != nullptr;
+    sc.iquads = (const float4*)c->d_iquads;
+    sc.ibig = (const uint2*)c->d_ibig;
+    sc.itris = (const float4*)c->d_itris;
+    sc.iinst = (const float4*)c->d_iinst;
+    sc.built_of = (const uint32_t*)c->d_built_of;
+    sc.itop_entry = w.itopEntry;
+    for (int k = 0; k < 3; k++) { sc.itop_min[k] = w.itopMin[k]; sc.itop_max[k] = w.itopMax[k]; sc.inst_reach[k] = w.instReach[k]; }
+    c->inst_ok = w.instanced;
     c->has_scene = true;
 }
 
+
+// ---- the scene as instances of meshes, beside the flattened scene (pt_build_scene_instanced)
+struct InstancedInput {
+    const void* mesh_tris; const int32_t* mesh_first; const int32_t* mesh_count; int32_t n_meshes;
+    const pt_instance* inst; int32_t n_inst;
+};
+
+// order: built position -> position in the host's list, of the flattened build (device).  w.d_in still holds the host's list.
+static int buildInstances(pt_ctx* c, SceneWork& w, uint32_t n, const InstancedInput& in, const uint32_t* order) {
+    const uint32_t nm = (uint32_t)in.n_meshes, ni = (uint32_t)in.n_inst;
+    // ---- the host's description must tile the flattened list: instance after instance, each as long as its mesh
+    uint32_t meshTris = 0;
+    for (uint32_t m = 0; m < nm; m++) {
+        if (in.mesh_first[m] < 0 || in.mesh_count[m] < 1) FAIL(c, PT_E_INVALID_ARG, "pt_build_scene_instanced: mesh %u has range [%d, +%d)", m, in.mesh_first[m], in.mesh_count[m]);
+        meshTris = std::max(meshTris, (uint32_t)in.mesh_first[m] + (uint32_t)in.mesh_count[m]);
+    }
+    std::vector<uint32_t> byFirst(ni), istart(ni + 1, 0);
+    for (uint32_t i = 0; i < ni; i++) {
+        byFirst[i] = i;
+        if (in.inst[i].mesh < 0 || (uint32_t)in.inst[i].mesh >= nm) FAIL(c, PT_E_INVALID_ARG, "pt_build_scene_instanced: instance %u names mesh %d of %u", i, in.inst[i].mesh, nm);
+        istart[i + 1] = istart[i] + (uint32_t)in.mesh_count[in.inst[i].mesh];
+    }
+    std::sort(byFirst.begin(), byFirst.end(), [&](uint32_t a, uint32_t b) { return in.inst[a].first_triangle < in.inst[b].first_triangle; });
+    long long cursor = 0;
+    for (uint32_t k = 0; k < ni; k++) {
+        const pt_instance& it = in.inst[byFirst[k]];
+        if (it.first_triangle != cursor) FAIL(c, PT_E_INVALID_ARG, "pt_build_scene_instanced: the instances do not tile the triangle list (instance %u starts at %d, expected %lld)", byFirst[k], it.first_triangle, cursor);
+        cursor += in.mesh_count[it.mesh];
+    }
+    if (cursor != (long long)n) FAIL(c, PT_E_INVALID_ARG, "pt_build_scene_instanced: the instances cover %lld triangles, the list has %u", cursor, n);
+
+    auto dev = [&](size_t bytes) -> void* { void* p = nullptr; if (ptMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr; w.scratch.push_back(p); return p; };
+#define NEED(ptr) do { if (!(ptr)) FAIL(c, PT_E_OOM, "pt_build_scene_instanced: out of device memory"); } while (0)
+    ptbuild::Tri112* d_mesh = (ptbuild::Tri112*)dev((size_t)meshTris * 112);
+    ptinst::HostInstance* d_inst = (ptinst::HostInstance*)dev((size_t)ni * 72);
+    int32_t* d_mfirst = (int32_t*)dev((size_t)nm * 4);
+    int32_t* d_mcount = (int32_t*)dev((size_t)nm * 4);
+    uint32_t* d_istart = (uint32_t*)dev((size_t)(ni + 1) * 4);
+    uint32_t* d_small = (uint32_t*)dev((size_t)(nm + 4) * 4);          // [0] mismatches, [4..] per-mesh stretch (float bits)
+    ptinst::InstWork* d_work = (ptinst::InstWork*)dev((size_t)ni * sizeof(ptinst::InstWork));
+    NEED(d_mesh); NEED(d_inst); NEED(d_mfirst); NEED(d_mcount); NEED(d_istart); NEED(d_small); NEED(d_work);
+    TRY(hipMemcpyAsync(d_mesh, in.mesh_tris, (size_t)meshTris * 112, hipMemcpyHostToDevice, c->stream));
+    TRY(hipMemcpyAsync(d_inst, in.inst, (size_t)ni * 72, hipMemcpyHostToDevice, c->stream));
+    TRY(hipMemcpyAsync(d_mfirst, in.mesh_first, (size_t)nm * 4, hipMemcpyHostToDevice, c->stream));
+    TRY(hipMemcpyAsync(d_mcount, in.mesh_count, (size_t)nm * 4, hipMemcpyHostToDevice, c->stream));
+    TRY(hipMemcpyAsync(d_istart, istart.data(), (size_t)(ni + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    TRY(hipMemsetAsync(d_small, 0, (size_t)(nm + 4) * 4, c->stream));
+    TRY(ptMalloc(&w.built_of, (size_t)n * 4));
+    hipLaunchKernelGGL(ptinst::k_invert, dim3(launchGrid(n)), dim3(256), 0, c->stream, order, n, (uint32_t*)w.built_of);
+    hipLaunchKernelGGL(ptinst::k_verify, dim3(launchGrid(istart[ni])), dim3(256), 0, c->stream, w.d_in, d_mesh, d_inst, d_mfirst, d_mcount, d_istart, ni, istart[ni], d_small);
+    hipLaunchKernelGGL(ptinst::k_instance_boxes, dim3(ni), dim3(64), 0, c->stream, w.d_in, d_inst, d_mcount, ni, d_work, d_small + 4);
+    std::vector<uint32_t> small(nm + 4);
+    TRY(hipMemcpyAsync(small.data(), d_small, (size_t)(nm + 4) * 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipStreamSynchronize(c->stream));   // also completes the copy of w.root that repackOnDevice queued
+    if (small[0]) FAIL(c, PT_E_INVALID_ARG, "pt_build_scene_instanced: %u triangles of the list are not their mesh triangle under the instance matrix (Vector3.Transform), bit for bit", small[0]);
+
+    // ---- how far the boxes must be widened (see rayOffInstances in pt_device.hpp)
+    ptrepack::QGrid grid;
+    ptrepack::gridOf(w.root.mn, w.root.mx, &grid);
+    float widest = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        widest = std::max(widest, w.root.mx[a] - w.root.mn[a]);
+        w.instReach[a] = grid.reach[a] < 0.0f ? -1.0f : grid.reach[a] / 8.0f;   // two (effective) extents around the middle
+    }
+    const float farthest = 1.7320508f * 2.5f * widest;   // from a ray origin within reach to any point of the scene
+    std::vector<float> padObj(nm);
+    for (uint32_t m = 0; m < nm; m++) {
+        float stretch;
+        memcpy(&stretch, &small[4 + m], 4);
+        if (!(stretch < 1.0e30f)) FAIL(c, PT_E_INVALID_ARG, "pt_build_scene_instanced: an instance of mesh %u has a singular matrix", m);
+        padObj[m] = 16.0f * 5.9604645e-8f * (farthest * stretch + 2.0f);   // + the mesh's own size below
+    }
+
+    // ---- one tree per mesh
+    struct MeshBuild { ptbuild::BNode* bn = nullptr; uint32_t* order = nullptr; ptbuild::Tri112* sorted = nullptr; uint32_t *flagA = nullptr, *idxA = nullptr, *flagB = nullptr, *idxB = nullptr;
+                       uint32_t nn = 0, levels = 0, quads = 0, bigs = 0, quadBase = 0, triBase = 0, bigBase = 0; ptbuild::BNode root{}; };
+    auto buildTree = [&](const ptbuild::Tri112* tris, uint32_t count, uint32_t triBase, MeshBuild& b) -> int {
+        b.sorted = (ptbuild::Tri112*)dev((size_t)count * 112);
+        ptbuild::Node32* nodesTmp = (ptbuild::Node32*)dev((size_t)(2 * count) * 32);
+        NEED(b.sorted); NEED(nodesTmp);
+        TRY(ptbuild::build(c->stream, tris, count, nodesTmp, b.sorted, &b.nn, &b.levels, &b.bn, &b.order));
+        w.scratch.push_back(b.bn);
+        w.scratch.push_back(b.order);
+        b.flagA = (uint32_t*)dev((size_t)b.nn * 4); b.idxA = (uint32_t*)dev((size_t)b.nn * 4);
+        b.flagB = (uint32_t*)dev((size_t)b.nn * 4); b.idxB = (uint32_t*)dev((size_t)b.nn * 4);
+        NEED(b.flagA); NEED(b.idxA); NEED(b.flagB); NEED(b.idxB);
+        b.triBase = triBase;
+        hipLaunchKernelGGL(ptinst::k_iflags, dim3(launchGrid(b.nn)), dim3(256), 0, c->stream, b.bn, b.nn, triBase, b.flagA, b.flagB);
+        TRY(ptrepack::exclusiveScan(c->stream, b.flagA, b.idxA, b.nn, &w.tmp, &w.tmpBytes));
+        TRY(ptrepack::exclusiveScan(c->stream, b.flagB, b.idxB, b.nn, &w.tmp, &w.tmpBytes));
+        uint32_t v[4] = {0, 0, 0, 0};
+        TRY(hipMemcpyAsync(&v[0], b.flagA + (b.nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&v[1], b.idxA + (b.nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&v[2], b.flagB + (b.nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&v[3], b.idxB + (b.nn - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        TRY(hipMemcpyAsync(&b.root, b.bn, sizeof(b.root), hipMemcpyDeviceToHost, c->stream));
+        TRY(hipStreamSynchronize(c->stream));   // v and b.root live until here
+        b.quads = v[0] + v[1];
+        b.bigs = v[2] + v[3];
+        return PT_OK;
+    };
+    std::vector<MeshBuild> meshes(nm);
+    uint32_t triBase = 0, deepest = 0;
+    for (uint32_t m = 0; m < nm; m++) {
+        const int rc = buildTree(d_mesh + in.mesh_first[m], (uint32_t)in.mesh_count[m], triBase, meshes[m]);
+        if (rc != PT_OK) return rc;
+        triBase += (uint32_t)in.mesh_count[m];
+        deepest = std::max(deepest, meshes[m].levels);
+        float size = 0.0f;
+        for (int a = 0; a < 3; a++) size = std::max(size, std::max(std::fabs(meshes[m].root.mn[a]), std::fabs(meshes[m].root.mx[a])));
+        padObj[m] += 16.0f * 5.9604645e-8f * 2.0f * size;
+    }
+    // ---- the tree over the instances' widened world boxes
+    float* d_pad = (float*)dev((size_t)nm * 4);
+    ptbuild::Tri112* d_prims = (ptbuild::Tri112*)dev((size_t)ni * 112);
+    NEED(d_pad); NEED(d_prims);
+    TRY(hipMemcpyAsync(d_pad, padObj.data(), (size_t)nm * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(ptinst::k_instance_prims, dim3(launchGrid(ni)), dim3(256), 0, c->stream, d_inst, d_work, d_pad, ni, d_prims);
+    MeshBuild top;
+    {
+        const int rc = buildTree(d_prims, ni, 0u, top);
+        if (rc != PT_OK) return rc;
+    }
+    if (top.bigs) FAIL(c, PT_E_BAD_BVH, "pt_build_scene_instanced: %u leaves of the tree over the instances hold more than %d instances (coinciding instances?)", top.bigs, PT_LEAF_MAX_COUNT);
+    if (3 * (((int)top.levels + 1) / 2) + 2 + 3 * (((int)deepest + 1) / 2) > PT_STACK_TOTAL)
+        FAIL(c, PT_E_BAD_BVH, "pt_build_scene_instanced: tree depths %u + %u exceed the traversal stack (%d entries)", top.levels, deepest, PT_STACK_TOTAL);
+    // ---- the shared arrays: the top-level tree's records first
+    uint32_t quadTotal = top.quads, bigTotal = 0;
+    for (MeshBuild& b : meshes) { b.quadBase = quadTotal; b.bigBase = bigTotal; quadTotal += b.quads; bigTotal += b.bigs; }
+    if (triBase >= PT_LEAF_MAX_FIRST || quadTotal >= PT_LEAF_MAX_FIRST) FAIL(c, PT_E_BAD_BVH, "pt_build_scene_instanced: %u mesh triangles, %u records", triBase, quadTotal);
+    TRY(ptMalloc(&w.iquads, std::max<size_t>((size_t)quadTotal, 1) * 128));
+    TRY(ptMalloc(&w.ibig, std::max<size_t>((size_t)bigTotal, 1) * 8));
+    TRY(ptMalloc(&w.itris, (size_t)triBase * 48));
+    TRY(ptMalloc(&w.iinst, (size_t)ni * 128));
+    hipLaunchKernelGGL(ptinst::k_irecords, dim3(launchGrid(top.nn)), dim3(256), 0, c->stream, top.bn, top.nn, top.idxA, top.idxB, top.flagB, 0u, 0u, 0u, 0.0f,
+                       (float4*)w.iquads, (uint2*)w.ibig);
+    std::vector<ptinst::MeshInfo> info(nm);
+    for (uint32_t m = 0; m < nm; m++) {
+        MeshBuild& b = meshes[m];
+        hipLaunchKernelGGL(ptinst::k_irecords, dim3(launchGrid(b.nn)), dim3(256), 0, c->stream, b.bn, b.nn, b.idxA, b.idxB, b.flagB, b.quadBase, b.triBase, b.bigBase, padObj[m],
+                           (float4*)w.iquads, (uint2*)w.ibig);
+        hipLaunchKernelGGL(ptinst::k_itris, dim3(launchGrid((uint32_t)in.mesh_count[m])), dim3(256), 0, c->stream, b.sorted, b.order, (uint32_t)in.mesh_count[m], b.triBase, (float4*)w.itris);
+        if (b.root.left >= 0) info[m].root_entry = b.quadBase + 1u;
+        else if (b.root.count <= PT_LEAF_MAX_COUNT + 1 && b.triBase + (uint32_t)b.root.first < PT_LEAF_MAX_FIRST)
+            info[m].root_entry = PT_LEAF_FLAG | ((uint32_t)(b.root.count - 1) << 27) | (b.triBase + (uint32_t)b.root.first);
+        else info[m].root_entry = PT_LEAF_FLAG | (15u << 27) | b.bigBase;   // the root is the tree's only (big) leaf: row 0 of its rows
+        for (int a = 0; a < 3; a++) { info[m].mn[a] = b.root.mn[a] - padObj[m]; info[m].mx[a] = b.root.mx[a] + padObj[m]; }
+    }
+    ptinst::MeshInfo* d_info = (ptinst::MeshInfo*)dev((size_t)nm * sizeof(ptinst::MeshInfo));
+    NEED(d_info);
+    TRY(hipMemcpyAsync(d_info, info.data(), (size_t)nm * sizeof(ptinst::MeshInfo), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(ptinst::k_iinst, dim3(launchGrid(ni)), dim3(256), 0, c->stream, d_inst, d_work, top.order, d_info, ni, (float4*)w.iinst);
+    TRY(hipGetLastError());
+    TRY(hipStreamSynchronize(c->stream));   // info (host) is read by the copy above
+    w.itopEntry = top.root.left >= 0 ? 1u : (PT_LEAF_FLAG | ((uint32_t)(top.root.count - 1) << 27) | (uint32_t)top.root.first);
+    for (int a = 0; a < 3; a++) { w.itopMin[a] = top.root.mn[a]; w.itopMax[a] = top.root.mx[a]; }
+    w.instanced = true;
+#undef NEED
+    return PT_OK;
+}
+
 static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out,
-                   int32_t node_capacity, int32_t* n_nodes, float* build_ms) {
+                   int32_t node_capacity, int32_t* n_nodes, float* build_ms, const InstancedInput* instanced = nullptr) {
     if (!c || n_mat < 0 || n_tri < 0 || (n_mat && !materials) || (n_tri && !triangles_in)) return PT_E_INVALID_ARG;
     if (c->group) {
         // every GPU builds its own replica (the build is deterministic: the trees are identical); the first hands the arrays back
@@ -1217,7 +1405,7 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
         return c->group->all(c, [&](pt_ctx* m) {
             const bool lead = m == first;
             return impl_build_scene(m, materials, n_mat, triangles_in, n_tri, lead ? triangles_out : nullptr, lead ? nodes_out : nullptr, node_capacity,
-                                    lead ? n_nodes : nullptr, lead ? build_ms : nullptr);
+                                    lead ? n_nodes : nullptr, lead ? build_ms : nullptr, instanced);
         });
     }
     const int32_t need = n_tri ? 2 * n_tri - 1 : 1;
@@ -1236,13 +1424,22 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
     w.eb = getEvent(c);
     if (w.ea) (void)hipEventRecord(w.ea, c->stream);
     uint32_t nn = 0, levels = 0;
-    TRY(ptbuild::build(c->stream, w.d_in, n, w.d_nodes, w.d_sorted, &nn, &levels, &w.bn));
-    (void)hipFree(w.d_in);
-    w.d_in = nullptr;
+    uint32_t* order = nullptr;
+    TRY(ptbuild::build(c->stream, w.d_in, n, w.d_nodes, w.d_sorted, &nn, &levels, &w.bn, instanced ? &order : nullptr));
+    if (order) w.scratch.push_back(order);
+    if (!instanced) {
+        (void)hipFree(w.d_in);
+        w.d_in = nullptr;
+    }
     if ((int)levels > PT_STACK_TOTAL || 3 * (((int)levels + 1) / 2) > PT_STACK_TOTAL)
         FAIL(c, PT_E_BAD_BVH, "BVH depth %u exceeds the traversal stack (%d entries)", levels, PT_STACK_TOTAL);
     const int rc = repackOnDevice(c, w, n, nn, materials, n_mat);
     if (rc != PT_OK) return rc;
+    if (instanced) {
+        if (n < 3) FAIL(c, PT_E_INVALID_ARG, "pt_build_scene_instanced: %u triangles", n);
+        const int ri = buildInstances(c, w, n, *instanced, order);
+        if (ri != PT_OK) return ri;
+    }
     if (w.eb) (void)hipEventRecord(w.eb, c->stream);
     if (triangles_out && n) TRY(hipMemcpyAsync(triangles_out, w.d_sorted, (size_t)n * 112, hipMemcpyDeviceToHost, c->stream));
     if (nodes_out) TRY(hipMemcpyAsync(nodes_out, w.d_nodes, (size_t)nn * 32, hipMemcpyDeviceToHost, c->stream));
@@ -1433,6 +1630,18 @@ int pt_trace_occluded(pt_ctx* c, const float* o_d, const float* tmax, int32_t n,
 int pt_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, float* o_d, uint32_t* pixel) { return guarded(c, "pt_generate_rays", [&]() -> int { return impl_generate_rays(c, frame_state112, n, o_d, pixel); }); }
 int pt_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t iters, float* avg_ms, int32_t* tri, float* t) { return guarded(c, "pt_bench_extend", [&]() -> int { return impl_bench_extend(c, o_d, n, iters, avg_ms, tri, t); }); }
 int pt_build_bvh(pt_ctx* c, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out, int32_t node_capacity, int32_t* n_nodes, float* build_ms) { return guarded(c, "pt_build_bvh", [&]() -> int { return impl_build_bvh(c, triangles_in, n_tri, triangles_out, nodes_out, node_capacity, n_nodes, build_ms); }); }
+int pt_build_scene_instanced(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri, const void* mesh_triangles, const int32_t* mesh_first,
+                             const int32_t* mesh_count, int32_t n_meshes, const pt_instance* instances, int32_t n_instances, float* build_ms) {
+    if (!c) return PT_E_INVALID_ARG;
+    if (!mesh_triangles || !mesh_first || !mesh_count || n_meshes < 1 || !instances || n_instances < 1) {
+        c->err = "pt_build_scene_instanced: null or empty mesh / instance arrays";
+        return PT_E_INVALID_ARG;
+    }
+    return guarded(c, "pt_build_scene_instanced", [&]() -> int {
+        const InstancedInput in{mesh_triangles, mesh_first, mesh_count, n_meshes, instances, n_instances};
+        return impl_build_scene(c, materials, n_mat, triangles_in, n_tri, nullptr, nullptr, 0, nullptr, build_ms, &in);
+    });
+}
 int pt_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, const void* triangles_in, int32_t n_tri, void* triangles_out, void* nodes_out, int32_t node_capacity, int32_t* n_nodes, float* build_ms) { return guarded(c, "pt_build_scene", [&]() -> int { return impl_build_scene(c, materials, n_mat, triangles_in, n_tri, triangles_out, nodes_out, node_capacity, n_nodes, build_ms); }); }
 
 }  // extern "C"

@@ -813,8 +813,9 @@ inline int grid(uint32_t n) { return (int)((n + PTB_BLOCK - 1) / PTB_BLOCK); }
 // Builds on `stream`.  d_tris: n triangles in insertion order.  On return d_nodes_out (capacity max(1, 2n-1)) and
 // d_tris_out (n) hold the reference's arrays.  Returns hipSuccess or the failing call's error.
 // keep_nodes (optional): receives the construction-order node array instead of it being freed (hipFree it).
+// keep_order (optional): receives the permutation (position in d_tris_out -> position in d_tris), n words (hipFree it).
 inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, Node32* d_nodes_out, Tri112* d_tris_out, uint32_t* n_nodes_out,
-                        uint32_t* levels_out, BNode** keep_nodes = nullptr) {
+                        uint32_t* levels_out, BNode** keep_nodes = nullptr, uint32_t** keep_order = nullptr) {
 #define PTB_TRY(x) do { err = (x); if (err != hipSuccess) goto done; } while (0)
     hipError_t err = hipSuccess;
     const uint32_t maxNodes = n ? 2u * n - 1u : 1u;
@@ -927,6 +928,7 @@ inline hipError_t build(hipStream_t stream, const Tri112* d_tris, uint32_t n, No
         *levels_out = levels > smallDepth ? levels : smallDepth;
     }
     if (keep_nodes) { *keep_nodes = nodes; nodes = nullptr; }
+    if (keep_order) { *keep_order = order[cur]; order[cur] = nullptr; }
 done:
     (void)hipFree(pmin); (void)hipFree(pmax); (void)hipFree(cent);
     for (int k = 0; k < 2; k++) { (void)hipFree(order[k]); (void)hipFree(bins[k]); (void)hipFree(active[k]); }

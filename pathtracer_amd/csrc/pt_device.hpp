@@ -89,6 +89,26 @@ struct DevScene {
     // the grid of qquads: plane = grid_min + cell number * grid_cell; rays that start farther than grid_reach from
     // grid_mid on some axis do not take the quantised walk (see rayOffGrid)
     float grid_min[3], grid_cell[3], grid_mid[3], grid_reach[3];
+    // ---- the same scene as instances of meshes (optional; pt_build_scene_instanced): a tree over the instances' world boxes whose
+    // leaves name instances, and one tree per mesh in the mesh's own space.  No reference counterpart: the reference flattens.
+    // iquads:   quad records (128 B, exact format) of the top-level tree, then of every mesh's tree; boxes widened by the error bound
+    //           of the ray's transformation (see rayOffInstances)
+    // ibig:     big-leaf rows of those trees
+    // itris:    48 B per mesh triangle in its tree's order: the three object-space positions; .w of the first = the triangle's
+    //           position in the mesh as the host listed it
+    // iinst:    128 B per instance in the top-level tree's order, eight float4: the instance matrix by columns with the translation
+    //           (M11 M21 M31 M41) (M12 M22 M32 M42) (M13 M23 M33 M43); the inverse A of its linear part by columns with the translation
+    //           again (A11 A21 A31 M41) (A12 A22 A32 M42) (A13 A23 A33 M43); (entry of the mesh tree's root, first flattened triangle of
+    //           the instance, mesh box min x, min y); (mesh box min z, max x, max y, max z) — the box widened like the tree's
+    // built_of: flattened triangle as the host listed it -> its index in the built flattened array (the id results carry)
+    const float4* iquads;
+    const uint2* ibig;
+    const float4* itris;
+    const float4* iinst;
+    const uint32_t* built_of;
+    uint32_t itop_entry;           // entry of the top-level tree's root
+    float itop_min[3], itop_max[3];
+    float inst_reach[3];           // rays starting farther than this from grid_mid take the flattened exact walk (< 0: all of them)
 };
 
 // Counters and queue sizes shared by the stages of one context (device memory).
@@ -260,6 +280,24 @@ __device__ __forceinline__ bool rayOffGrid(const DevScene& sc, f3 o, f3 d) {
     return !(dOk && oOk);
 }
 
+// Which records traverseWave walks.
+#define PT_WALK_EXACT 0
+#define PT_WALK_QUANT 1
+#define PT_WALK_INST 2
+// The instanced walk moves the ray into a mesh's space: o' = (o - T) A, d' = d A with A the inverse of the instance matrix's
+// linear part, no renormalisation, so distances along the ray stay what they are in the world.  The rounding of that
+// transformation and of the slab test on it displaces a box plane by at most ~10 * 2^-24 * (|o - T| / scale + 2) mesh units; the
+// mesh trees' boxes are widened by 16 * 2^-24 * that bound taken at inst_reach (two scene extents around the scene's middle), and the
+// top-level boxes by the same amount in world units.  Rays that start farther out, or can produce NaN slab distances, take the
+// exact two-wide walk over the flattened scene.  Triangles are always tested in world space, on vertices re-derived from the
+// mesh vertex and the instance matrix with the host's own expression (Vector3.Transform: ((x M11 + y M21) + z M31) + M41), which
+// reproduces the flattened triangle bit for bit: a hit's distance and barycentrics are those of the flattened walk.
+__device__ __forceinline__ bool rayOffInstances(const DevScene& sc, f3 o) {
+    return !(fabsf(o.x - sc.grid_mid[0]) <= sc.inst_reach[0] && fabsf(o.y - sc.grid_mid[1]) <= sc.inst_reach[1] &&
+             fabsf(o.z - sc.grid_mid[2]) <= sc.inst_reach[2]);
+}
+#define PT_SENTINEL 0x7FFFFFFFu   // stack entry below the entries of a mesh's tree: popping it takes the ray back to the world
+
 // ------------------------------------------------------------------ traversal
 struct HitRec { float t; int32_t tri; float u, v; };
 
@@ -374,6 +412,9 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 #ifndef PT_LEAF_BATCH
 #define PT_LEAF_BATCH 12
 #endif
+#ifndef PT_ENTER_BATCH
+#define PT_ENTER_BATCH 8     // INST: lanes waiting to enter an instance that make the wave run an enter phase
+#endif
 #define PT_NO_RAY 0xFFFFFFFFu
 #ifndef PT_GRAB_LARGE
 #define PT_GRAB_LARGE 256u
@@ -398,12 +439,13 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 #define PT_MARK(name)
 #endif
 
-template <bool ANYHIT, bool STATS, bool QUANT, class Source>
+template <bool ANYHIT, bool STATS, int MODE, class Source>
 __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, unsigned long long* leafq, const Source& src,
                                              uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched, uint32_t refillMin,
                                              unsigned long long* specialRays) {
     // sched[0..2] (STATS builds): wave iterations spent on interior steps, leaf steps, retire/refill; sched[3..4]: distinct quad
     // records / triangles fetched per wave instruction, summed (wave-uniform counts)
+    constexpr bool QUANT = MODE == PT_WALK_QUANT, INST = MODE == PT_WALK_INST;
     const uint32_t lane = laneId();
     const uint32_t totalWaves = gridDim.x * (blockDim.x / PT_WAVE);
     const uint32_t waveId = blockIdx.x * (blockDim.x / PT_WAVE) + threadIdx.x / PT_WAVE;
@@ -420,6 +462,11 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
     uint32_t rayIdx = PT_NO_RAY;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv = mk3(0, 0, 0);
     f3 qa = mk3(0, 0, 0), qb = mk3(0, 0, 0);   // QUANT: distance of grid plane number q on an axis = fma(q, qa, qb)
+    // INST: origin and reciprocal direction in the space the ray is in (world, or a mesh's); the other walks have the world's only
+    f3 ocStore = mk3(0, 0, 0), invcStore = mk3(0, 0, 0);
+    f3& oc = INST ? ocStore : o;
+    f3& invc = INST ? invcStore : inv;
+    int32_t instSlot = -1;                     // INST: the instance the ray is inside, -1 at the top level
     float best = PT_INF, bu = 0.0f, bv = 0.0f, tlimit = PT_INF;
     int32_t bestTri = -1;
     bool occluded = false, special = false;
@@ -441,7 +488,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
         leafJ = (int32_t)low;
         leafEnd = (int32_t)(low + cm1 + 1u);
         if ((e >> 27) == 31u) {   // leaf too big to pack: `low` is its row in the side table
-            const uint2 rec = sc.big[low];
+            const uint2 rec = (INST && !special) ? sc.ibig[low] : sc.big[low];
             leafJ = (int32_t)rec.x;
             leafEnd = (int32_t)(rec.x + rec.y);
         }
@@ -457,6 +504,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             // opaque to the optimiser: otherwise the LDS and scratch reads are merged into one flat access
             asm volatile("" : "+v"(r.x), "+v"(r.y));
             if (sp >= PT_STACK_LDS) r = spill[sp - PT_STACK_LDS];
+            if (INST && r.x == PT_SENTINEL) { instSlot = -1; oc = o; invc = inv; continue; }   // the mesh's tree is done: back to the world
             if (ANYHIT || !(__uint_as_float(r.y) > best)) { next = r.x; break; }
         }
         enter(next);
@@ -468,6 +516,38 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
         else if (room) spill[sp - PT_STACK_LDS] = r;
         sp += room ? 1 : 0;
         if (!room) *overflow += 1u;   // the subtree is dropped; counted, never silent
+    };
+    // INST: a ray on a leaf of the top-level tree enters the leaf's first instance (the others go back on the stack as a shorter
+    // leaf), with a marker below everything the mesh's tree will push.  An instance whose mesh box the transformed ray misses is left
+    // again on the spot.  Like the triangle tests this runs as a phase of the wave, for all the lanes that wait for it.
+    // whether the lane's current entry is a leaf of the top-level tree (INST): such lanes wait for an enter phase, not a leaf phase
+    auto atInstance = [&]() { return INST && (int32_t)cur < 0 && instSlot < 0 && !special; };
+    auto enterInstances = [&]() {
+        if (atInstance()) {
+            const uint32_t e = cur;
+            uint32_t first = e & (PT_LEAF_MAX_FIRST - 1u), count = ((e >> 27) & 15u) + 1u;
+            if ((e >> 27) == 31u) { const uint2 rec = sc.ibig[first]; first = rec.x; count = rec.y; }
+            // the rest of the leaf as a packed entry (leaves of the top-level tree hold at most PT_LEAF_MAX_COUNT + 1 instances: a scene
+            // whose top-level tree has a longer one is not installed as instances)
+            if (count > 1u) push(PT_LEAF_FLAG | ((count - 2u) << 27) | (first + 1u), 0.0f);
+            push(PT_SENTINEL, 0.0f);
+            const float4* rec = sc.iinst + 8 * (size_t)first;
+            const float4 a0 = rec[3], a1 = rec[4], a2 = rec[5], m6 = rec[6], m7 = rec[7];
+            instSlot = (int32_t)first;
+            const f3 rel = mk3(o.x - a0.w, o.y - a1.w, o.z - a2.w);
+            oc = mk3((rel.x * a0.x + rel.y * a0.y) + rel.z * a0.z, (rel.x * a1.x + rel.y * a1.y) + rel.z * a1.z, (rel.x * a2.x + rel.y * a2.y) + rel.z * a2.z);
+            const f3 dc = mk3((d.x * a0.x + d.y * a0.y) + d.z * a0.z, (d.x * a1.x + d.y * a1.y) + d.z * a1.z, (d.x * a2.x + d.y * a2.y) + d.z * a2.z);
+            // the reciprocal need not be the correctly rounded one: the mesh trees' boxes are widened for more than its last bit
+            invc = mk3(__builtin_amdgcn_rcpf(dc.x), __builtin_amdgcn_rcpf(dc.y), __builtin_amdgcn_rcpf(dc.z));
+            float tm, tx;
+            slabRange(m6.z, m6.w, m7.x, m7.y, m7.z, m7.w, oc, invc, &tm, &tx);
+            const float tc = tm > 0.0f ? tm : 0.0f;
+            // (a direction component that is exactly zero in the mesh's space, with the origin exactly on a box plane of that axis, makes
+            // 0 * inf = NaN, which v_min / v_max drop: that axis then constrains nothing or everything — a set of rays of measure zero)
+            const bool in = tc < tx && (ANYHIT ? tm < tlimit : !(tc > best));
+            if (in) enter(__float_as_uint(m6.x));
+            else popNext();
+        }
     };
 
     for (;;) {
@@ -481,6 +561,8 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                 if (rayIdx != PT_NO_RAY && cur == 0u) {
                     HitRec h;
                     h.t = best; h.tri = bestTri; h.u = bu; h.v = bv;
+                    // the instanced walk names a triangle by its place in the host's list; results carry its index in the built array
+                    if (INST && !special && bestTri >= 0) h.tri = (int32_t)sc.built_of[bestTri];
                     src.store(rayIdx, h, occluded);
                     rayIdx = PT_NO_RAY;
                 }
@@ -511,14 +593,26 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                         qa = mk3(sc.grid_cell[0] * inv.x, sc.grid_cell[1] * inv.y, sc.grid_cell[2] * inv.z);
                         qb = mk3((sc.grid_min[0] - o.x) * inv.x, (sc.grid_min[1] - o.y) * inv.y, (sc.grid_min[2] - o.z) * inv.z);
                     }
+                    if (INST) {
+                        special = special || rayOffInstances(sc, o);
+                        oc = o;
+                        invc = inv;
+                        instSlot = -1;
+                    }
                     float tr;
                     // the root test is done once per ray: always the NaN-propagating form
-                    const bool in = sc.n_nodes > 0 &&
-                                    slabTest<true>(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], o, inv, &tr);
                     cur = 0;
-                    if (in) {
-                        if (sc.root_count > 0) { cur = PT_LEAF_FLAG; leafJ = sc.root_left; leafEnd = sc.root_left + sc.root_count; }
-                        else cur = special ? (uint32_t)sc.root_left : 1u;   // the node index of the root's left child (two-wide walk), or quad 0
+                    if (INST && !special) {
+                        if (sc.n_nodes > 0 && slabTest<true>(sc.itop_min[0], sc.itop_min[1], sc.itop_min[2], sc.itop_max[0], sc.itop_max[1], sc.itop_max[2], o, inv, &tr)) {
+                            enter(sc.itop_entry);
+                        }
+                    } else {
+                        const bool in = sc.n_nodes > 0 &&
+                                        slabTest<true>(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], o, inv, &tr);
+                        if (in) {
+                            if (sc.root_count > 0) { cur = PT_LEAF_FLAG; leafJ = sc.root_left; leafEnd = sc.root_left + sc.root_count; }
+                            else cur = special ? (uint32_t)sc.root_left : 1u;   // the node index of the root's left child (two-wide walk), or quad 0
+                        }
                     }
                 }
                 {
@@ -533,9 +627,10 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
         // ---- interior steps, for as long as that is the wave's kind of work
         for (;;) {
             const unsigned long long interiorMask = __ballot((int32_t)cur > 0);
-            const uint32_t nLeaf = (uint32_t)__popcll(__ballot((int32_t)cur < 0));
-            if (interiorMask == 0ull || nLeaf >= PT_LEAF_BATCH) break;
-            if (refillable && 64u - (uint32_t)__popcll(interiorMask) - nLeaf >= refillMin) break;
+            const uint32_t nEnter = INST ? (uint32_t)__popcll(__ballot(atInstance())) : 0u;
+            const uint32_t nLeaf = (uint32_t)__popcll(__ballot((int32_t)cur < 0)) - nEnter;
+            if (interiorMask == 0ull || nLeaf >= PT_LEAF_BATCH || nEnter >= PT_ENTER_BATCH) break;
+            if (refillable && 64u - (uint32_t)__popcll(interiorMask) - nLeaf - nEnter >= refillMin) break;
             if (STATS) sched[0]++;
             PT_MARK("interior_begin");
             if (STATS) {
@@ -585,14 +680,14 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                         PT_QUANT_CHILD(k3, w0.y >> 16, w0.w >> 16, w1.y >> 16, w1.w >> 16, w2.y >> 16, w2.w >> 16, 3u)
 #undef PT_QUANT_CHILD
                     } else {
-                        const float4* p = sc.quads + 8 * (size_t)(cur - 1u);
+                        const float4* p = (INST ? sc.iquads : sc.quads) + 8 * (size_t)(cur - 1u);
                         const float4 mnx = p[0], mny = p[1], mnz = p[2], mxx = p[3], mxy = p[4], mxz = p[5];
                         const float4 eb = p[6];
                         e0 = __float_as_uint(eb.x); e1 = __float_as_uint(eb.y); e2 = __float_as_uint(eb.z); e3 = __float_as_uint(eb.w);
 #define PT_QUAD_CHILD(K, C, SLOT)                                                                             \
                     {                                                                                          \
                         float tm, tx;                                                                          \
-                        slabRange(mnx.C, mny.C, mnz.C, mxx.C, mxy.C, mxz.C, o, inv, &tm, &tx);                 \
+                        slabRange(mnx.C, mny.C, mnz.C, mxx.C, mxy.C, mxz.C, INST ? oc : o, INST ? invc : inv, &tm, &tx); \
                         PT_QUAD_KEY(K, tm, tx, SLOT)                                                           \
                     }
                         PT_QUAD_CHILD(k0, x, 0u)
@@ -660,20 +755,26 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                 }
             }
         }
+        // ---- INST: the lanes waiting on a leaf of the top-level tree enter their instances (when enough wait, or nobody is left stepping)
+        if (INST) {
+            const uint32_t nEnter = (uint32_t)__popcll(__ballot(atInstance()));
+            const uint32_t nInterior = (uint32_t)__popcll(__ballot((int32_t)cur > 0));
+            if (nEnter != 0u && (nInterior == 0u || nEnter >= PT_ENTER_BATCH)) enterInstances();
+        }
         // ---- triangle tests, one per waiting lane and iteration
         for (;;) {
-            const unsigned long long leafMask = __ballot((int32_t)cur < 0);
+            const unsigned long long leafMask = __ballot((int32_t)cur < 0 && !atInstance());
             if (leafMask == 0ull) break;
             const uint32_t nLeaf = (uint32_t)__popcll(leafMask);
             const uint32_t nInterior = (uint32_t)__popcll(__ballot((int32_t)cur > 0));
             if (nInterior != 0u && nLeaf < PT_LEAF_BATCH) break;
-            if (refillable && 64u - nInterior - nLeaf >= refillMin) break;
+            if (refillable && 64u - nInterior - nLeaf - (INST ? (uint32_t)__popcll(__ballot(atInstance())) : 0u) >= refillMin) break;
             if (STATS) sched[1]++;
             PT_MARK("leaf_begin");
             unsigned long long* const resKey = leafq;                       // [64] best (distance bits, triangle) per owner
             float2* const resUv = (float2*)(leafq + 64);                    // [64] its barycentrics
             uint32_t* const ownerOf = (uint32_t*)(leafq + 128);             // [64] owner lane of each dealt triangle
-            const bool owner = (int32_t)cur < 0;
+            const bool owner = (int32_t)cur < 0 && !atInstance();
             if (owner && leafEnd == 0) unpackLeaf();
             const uint32_t left = owner ? (uint32_t)(leafEnd - leafJ) : 0u;
             const uint32_t cnt = left < 64u ? left : 64u;
@@ -707,7 +808,35 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     sched[4]++;
                 }
             }
-            if (QUANT) {
+            uint32_t cand = (uint32_t)j;   // what identifies the triangle in the result key
+            if (INST) {
+                // the owner's ray is inside an instance: the triangle is the mesh's, placed by the instance matrix with the host's
+                // expression (Vector3.Transform, row vectors: ((x M11 + y M21) + z M31) + M41), which gives the flattened triangle's
+                // vertices bit for bit; the test itself is the world-space one.  Owners on the flattened exact walk test flattened triangles.
+                const int32_t slotO = __shfl(instSlot, (int)own);
+                const bool flatO = __shfl((int)special, (int)own) != 0;
+                if (busy) {
+                    float4 q0, q1, q2;
+                    if (flatO) {
+                        const float4* tp = sc.tri_hot + 3 * (size_t)j;
+                        q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
+                    } else {
+                        const float4* tp = sc.itris + 3 * (size_t)j;
+                        const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                        const float4* rec = sc.iinst + 8 * (size_t)slotO;
+                        const float4 c0 = rec[0], c1 = rec[1], c2 = rec[2], m6 = rec[6];
+#define PT_PLACE(P) mk3(((P.x * c0.x + P.y * c0.y) + P.z * c0.z) + c0.w, ((P.x * c1.x + P.y * c1.y) + P.z * c1.z) + c1.w, ((P.x * c2.x + P.y * c2.y) + P.z * c2.z) + c2.w)
+                        const f3 w1 = PT_PLACE(p0), w2 = PT_PLACE(p1), w3 = PT_PLACE(p2);
+#undef PT_PLACE
+                        q0 = make_float4(w1.x, w1.y, w1.z, 0.0f);
+                        q1 = make_float4(w2.x - w1.x, w2.y - w1.y, w2.z - w1.z, 0.0f);     // Triangle.cs:17-18, as the hot records hold them
+                        q2 = make_float4(w3.x - w1.x, w3.y - w1.y, w3.z - w1.z, 0.0f);
+                        cand = __float_as_uint(m6.y) + __float_as_uint(p0.w);                // the triangle's place in the flattened array as the host listed it
+                    }
+                    hit = triangleTest(q0, q1, q2, po, pd, &tt, &tu, &tv);
+                    if (ANYHIT) hit = hit && tt < limO;
+                }
+            } else if (QUANT) {
                 // the walk came here through widened boxes: the leaf's own box (Node.Bounds, verbatim) decides whether its
                 // triangles are eligible, by the reference's slab test and the walk's distance rule.  Owners on the exact
                 // two-wide walk have applied both already.
@@ -732,7 +861,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                 if (ANYHIT) hit = hit && tt < limO;
             }
             // closest: smallest (distance, triangle index); any-hit: first occluder in index order
-            const unsigned long long key = ANYHIT ? (unsigned long long)kth : (((unsigned long long)__float_as_uint(tt) << 32) | (uint32_t)j);
+            const unsigned long long key = ANYHIT ? (unsigned long long)kth : (((unsigned long long)__float_as_uint(tt) << 32) | cand);
             if (hit) atomicMin(&resKey[own], key);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -120,8 +120,9 @@ struct ExtendSource {
     }
 };
 
-template <bool STATS, bool QUANT>
-__global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
+// the instanced walk carries a second ray (the one in the mesh's space) and is compiled for one wave per SIMD less
+template <bool STATS, int MODE>
+__global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_WAVES - 1 : (MODE == PT_WALK_QUANT ? PT_TRAVERSE_WAVES + 1 : PT_TRAVERSE_WAVES)) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_extend(DevScene
     src.d = q.d[cur];
     src.hit = q.hit;
     uint32_t sched[5] = {0, 0, 0, 0, 0};
-    traverseWave<false, STATS, QUANT>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
+    traverseWave<false, STATS, MODE>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
     if (STATS) {
         waveAdd64(&ctl->extend_steps, steps);
         waveAdd64(&ctl->extend_tris, tris);
@@ -176,8 +177,8 @@ struct ConnectSource {
     }
 };
 
-template <bool STATS, bool QUANT>
-__global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
+template <bool STATS, int MODE>
+__global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_WAVES - 1 : PT_TRAVERSE_WAVES) k_connect(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(PT_BLOCK, PT_TRAVERSE_WAVES) k_connect(DevScen
     src.sc = q.sc;
     src.plane = q.plane;
     uint32_t sched[5] = {0, 0, 0, 0, 0};
-    traverseWave<true, STATS, QUANT>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
+    traverseWave<true, STATS, MODE>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
     if (STATS) {
         waveAdd64(&ctl->shadow_steps, steps);
         waveAdd64(&ctl->shadow_tris, tris);
@@ -545,7 +546,7 @@ struct TraceSource {
 };
 
 // One wave per 64 rays (grid sized by the caller), no shared cursor.
-template <bool ANYHIT, bool QUANT>
+template <bool ANYHIT, int MODE>
 __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src, int n, Ctl* ctl) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
@@ -554,7 +555,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src
     uint32_t steps = 0, tris = 0, overflow = 0;
     uint32_t sched[5] = {0, 0, 0, 0, 0};
     // every wave traces its own 64 rays and never refills: the threshold is not used
-    traverseWave<ANYHIT, false, QUANT>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, 64u, &ctl->special_rays);
+    traverseWave<ANYHIT, false, MODE>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, 64u, &ctl->special_rays);
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
 }
 

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 from . import _native
-from .types import FRAME_STATE, MATERIAL, NODE, TRIANGLE
+from .types import FRAME_STATE, INSTANCE, MATERIAL, NODE, TRIANGLE
 
 ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "meshes.bin")
 
@@ -44,6 +44,7 @@ def _lib():
         lib.pth_scene_counts.argtypes = [vp, vp]
         lib.pth_scene_references.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
         lib.pth_scene_arrays.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+        lib.pth_scene_instancing.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), vp, vp, vp, vp]
         lib.pth_camera_basis.argtypes = [vp, vp, vp, vp, vp]
         lib.pth_camera_state.argtypes = [vp, vp, vp, vp, C.c_float, i32, i32, vp, C.POINTER(C.c_float)]
         lib.pth_image_write.argtypes = [C.c_char_p, vp, i32, i32, i32, i32, C.c_float]
@@ -147,6 +148,17 @@ class Scene:
                 return np.zeros(0, dt)
             return np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(ptr.value), dtype=dt, count=n).copy()
         return view(pm, nm.value, MATERIAL), view(pt, nt.value, TRIANGLE)
+
+    def instancing(self):
+        """The scene as meshes and instances (see pth_scene_instancing): (mesh_triangles, mesh_first, mesh_count, instances) for
+        Wavefront.build_scene_instanced; instances is a structured array (transform 16 floats, mesh, first_triangle)."""
+        nm, nt, ni = C.c_int32(), C.c_int32(), C.c_int32()
+        _chk(self._lib.pth_scene_instancing(self._h, C.byref(nm), C.byref(nt), C.byref(ni), None, None, None, None))
+        tris = np.zeros(nt.value, TRIANGLE)
+        first, count = np.zeros(nm.value, np.int32), np.zeros(nm.value, np.int32)
+        inst = np.zeros(ni.value, INSTANCE)
+        _chk(self._lib.pth_scene_instancing(self._h, None, None, None, _p(tris), _p(first), _p(count), _p(inst)))
+        return tris, first, count, inst
 
     def arrays(self):
         """Copies of (Material[], Triangle[], Node[]) — what Scene.CopyToDevice uploads."""

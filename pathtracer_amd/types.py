@@ -18,6 +18,10 @@ RENDER_STATE = np.dtype([("width", "<i4"), ("height", "<i4"), ("pad", "<i4", 2),
 FRAME_STATE = np.dtype([("frames", "<i4"), ("samples", "<i4"), ("focal_distance", "<f4"), ("pad", "<i4"),
                         ("camera", CAMERA_STATE)])
 
+# pt_instance of pt_hip.h: a mesh placed by a System.Numerics Matrix4x4 (row-vector convention), its triangles' start in the flattened array
+INSTANCE = np.dtype([("transform", "<f4", 16), ("mesh", "<i4"), ("first_triangle", "<i4")])
+
+assert INSTANCE.itemsize == 72
 assert NODE.itemsize == 32 and VERTEX.itemsize == 32 and TRIANGLE.itemsize == 112 and MATERIAL.itemsize == 48
 assert CAMERA_STATE.itemsize == 96 and RENDER_STATE.itemsize == 32 and FRAME_STATE.itemsize == 112
 

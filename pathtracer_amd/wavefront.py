@@ -159,6 +159,20 @@ class Wavefront:
         self._check(self._lib.pt_build_scene(self._h, _ptr(mats), mats.size, _ptr(tris), n, _ptr(out_t), _ptr(out_n), cap, C.byref(nn), C.byref(ms)))
         return (out_t, out_n[:nn.value].copy(), ms.value) if want_arrays else ms.value
 
+    def build_scene_instanced(self, materials, triangles, mesh_triangles, mesh_first, mesh_count, instances):
+        """pt_build_scene plus the scene as instances of meshes (pt_build_scene_instanced); the arguments after `triangles` are
+        what host.Scene.instancing() returns.  set_option(10, 1) then makes the kernels walk the instances.  Returns device ms."""
+        from .types import INSTANCE, MATERIAL, TRIANGLE
+        mats = np.ascontiguousarray(materials, MATERIAL)
+        tris = np.ascontiguousarray(triangles, TRIANGLE)
+        mtris = np.ascontiguousarray(mesh_triangles, TRIANGLE)
+        first, count = np.ascontiguousarray(mesh_first, np.int32), np.ascontiguousarray(mesh_count, np.int32)
+        inst = np.ascontiguousarray(instances, INSTANCE)
+        ms = C.c_float()
+        self._check(self._lib.pt_build_scene_instanced(self._h, _ptr(mats), mats.size, _ptr(tris), tris.size, _ptr(mtris), _ptr(first), _ptr(count), first.size,
+                                                       _ptr(inst), inst.size, C.byref(ms)))
+        return ms.value
+
     def stats(self):
         s = _native.pt_stats()
         s.struct_size = C.sizeof(_native.pt_stats)
