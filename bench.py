@@ -191,7 +191,15 @@ class Run:
         else:
             self.wf = pa.Wavefront(device=local_rank, nee=bool(nee), rng_mode=1, tile_rank=rank, tile_world=world,
                                    samples_per_batch=args.batch, stage_timing=1)
-        self.wf.upload_scene(self.mats, self.tris, self.nodes)
+        self.instanced = bool(getattr(args, "instanced", 0))
+        if self.instanced:
+            # the same scene, built on the GPU, with the tree over instances beside the flattened one; the kernels walk the instances
+            mats, refs = scene.references()
+            self.wf.build_scene_instanced(mats, refs, *scene.instancing())
+            self.wf.set_option(10, 1)
+            self.quant = False
+        else:
+            self.wf.upload_scene(self.mats, self.tris, self.nodes)
         if args.blocks >= 0:
             self.wf.set_option(6, args.blocks)
         if args.refill_primary:
@@ -398,6 +406,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only for rehearsing N > 1 on a single GPU")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--quant", type=int, default=2, choices=[0, 1, 2], help="node records the traversal walks: 0 exact 128-byte, 1 quantised 64-byte, 2 the library's rule")
+    ap.add_argument("--instanced", action="store_true", help="walk the scene as instances of meshes (pt_build_scene_instanced + PT_OPT_INSTANCED): opt-in mode, "
+                    "same hit distances, see pt_hip.h")
     ap.add_argument("--in-process", action="store_true", help="N GPUs behind ONE context in this one process (pt_config.device_count = N: tile sharding and the "
                     "RCCL gather inside libpt_hip.so) instead of one process per GPU")
     args = ap.parse_args()
@@ -491,7 +501,7 @@ def main():
                        "nee": run.nee, "triangles": int(run.tris.size), "nodes": int(run.nodes.size),
                        "tiles": (f"8x8 groups round-robin over {args.in_process} GPUs behind one context (pt_config.device_count), gather + read-out inside the timed region"
                                  if args.in_process else f"8x8 groups round-robin over {world} rank(s)"),
-                       "node_records": "quantised, 64 B" if run.quant else "exact, 128 B",
+                       "node_records": "instances of meshes (two-level), exact 128 B" if run.instanced else ("quantised, 64 B" if run.quant else "exact, 128 B"),
                        "rays_per_step": (extend_rays + shadow_rays) / args.steps,
                        "extend_rays_per_step": extend_rays / args.steps, "shadow_rays_per_step": shadow_rays / args.steps},
             "roofline": roof,

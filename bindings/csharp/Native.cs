@@ -29,9 +29,17 @@ namespace PathTracer
             public ulong SchedInterior, SchedLeaf, SchedRefill, SpecialRays, ExtendUniqueSteps, ExtendUniqueTris, DeviceAllocations;
         }
 
+        // pt_instance: a mesh placed by a System.Numerics.Matrix4x4 (row vectors, translation in M41..M43), 72 bytes
+        [StructLayout(LayoutKind.Sequential)]
+        public struct Instance
+        {
+            public System.Numerics.Matrix4x4 Transform;
+            public int Mesh, FirstTriangle;
+        }
+
         // PT_OPT_* keys of pt_set_option
         public const int OptNee = 1, OptRngMode = 2, OptTraversalStats = 3, OptStageTiming = 4, OptSamplesPerBatch = 5,
-                         OptTraverseBlocksPerCu = 6, OptRefillPrimary = 7, OptRefillBounce = 8, OptQuantized = 9;
+                         OptTraverseBlocksPerCu = 6, OptRefillPrimary = 7, OptRefillBounce = 8, OptQuantized = 9, OptInstanced = 10;
 
         [DllImport(Lib)] public static extern int pt_default_config(ref Config cfg);
         [DllImport(Lib)] public static extern int pt_create(ref Config cfg, out IntPtr ctx);
@@ -50,6 +58,9 @@ namespace PathTracer
                                                                Node[] nodesOut, int nodeCapacity, out int nNodes, out float buildMs);
         [DllImport(Lib)] public static extern int pt_build_scene(IntPtr ctx, Material[] materials, int nMaterials, Triangle[] trianglesIn, int nTriangles,
                                                                  Triangle[] trianglesOut, Node[] nodesOut, int nodeCapacity, out int nNodes, out float buildMs);
+        [DllImport(Lib)] public static extern int pt_build_scene_instanced(IntPtr ctx, Material[] materials, int nMaterials, Triangle[] trianglesIn, int nTriangles,
+                                                                           Triangle[] meshTriangles, int[] meshFirst, int[] meshCount, int nMeshes,
+                                                                           Instance[] instances, int nInstances, out float buildMs);
         [DllImport(Lib)] public static extern int pt_trace_closest_noalloc(IntPtr ctx, float[] originDirection, int n, int[] tri, float[] t, float[] uv);
         [DllImport(Lib)] public static extern int pt_trace_occluded(IntPtr ctx, float[] originDirection, float[] tmax, int n, byte[] occluded);
         [DllImport(Lib)] public static extern int pt_set_option(IntPtr ctx, int key, int value);

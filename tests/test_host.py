@@ -458,3 +458,27 @@ def test_isa_cost_file_is_current():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_cost.py"), "--check"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_scene_as_meshes_and_instances():
+    """pth_scene_instancing (input of pt_build_scene_instanced): the instances tile the flattened triangle list in order, and
+    Vector3.Transform(mesh vertex, instance matrix) — ((x M11 + y M21) + z M31) + M41, Mesh.cs:50-70 — reproduces every flattened
+    vertex bit for bit, for the instanced-bunny generator and for the bundled recipe (scale applied after the translation)."""
+    from pathtracer_amd.host import Scene
+    for make in (lambda s: s.generate_instances(30, 11), lambda s: s.initialize_scene(11)):
+        s = Scene()
+        make(s)
+        _, refs = s.references()
+        tris, first, count, inst = s.instancing()
+        cursor = 0
+        for it in inst:
+            m, n = int(it["mesh"]), int(count[it["mesh"]])
+            assert int(it["first_triangle"]) == cursor
+            cursor += n
+            M = it["transform"].reshape(4, 4).astype(np.float32)
+            mesh, flat = tris[first[m]:first[m] + n], refs[cursor - n:cursor]
+            for v in ("v1", "v2", "v3"):
+                p = mesh[v]["position"].astype(np.float32)
+                w = np.stack([((p[:, 0] * M[0, a] + p[:, 1] * M[1, a]) + p[:, 2] * M[2, a]) + M[3, a] for a in range(3)], 1).astype(np.float32)
+                assert np.array_equal(w.view(np.uint32), flat[v]["position"].view(np.uint32))
+        assert cursor == refs.size

@@ -19,7 +19,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def counters(path, kernel="void k_extend<false, false>"):
+def counters(path, kernel="void k_extend<false, 0>"):
     vals = {}
     for line in open(path):
         m = re.match(re.escape(kernel) + r"\s+(\S+)\s+mean/dispatch\s+([\d.]+)", line)
@@ -59,7 +59,7 @@ def main():
         summary = os.path.join(out, f"{run}_pmc_{w}_summary.txt")
         shutil.copy(summary, os.path.join(prof, f"{tag}_bench_{w}_pmc.txt"))
         # the headline scene is walked through the exact records, the soup (a tree beyond L2) through the quantised ones
-        kernel = "void k_extend<false, true>" if w == "c3" else "void k_extend<false, false>"
+        kernel = "void k_extend<false, 1>" if w == "c3" else "void k_extend<false, 0>"
         traffic[w] = traffic_entry(counters(summary, kernel), f"profiles/{tag}_bench_{w}_pmc.txt", "python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-secondary" + args)
         stats = sorted(glob.glob(os.path.join(out, f"{run}_pmc_{w}", "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
         shutil.copy(stats[-1], os.path.join(prof, f"{tag}_bench_{w}_kernel_stats.csv"))

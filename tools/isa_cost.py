@@ -23,9 +23,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "pathtracer_amd", "isa_cost.json")
-KERNELS = {"k_extend": "_Z8k_extendILb0ELb0EE", "k_connect": "_Z9k_connectILb0ELb0EE",
+KERNELS = {"k_extend": "_Z8k_extendILb0ELi0EE", "k_connect": "_Z9k_connectILb0ELi0EE",
            # the same kernels over the quantised 64-byte node records (trees beyond L2)
-           "k_extend_quant": "_Z8k_extendILb0ELb1EE", "k_connect_quant": "_Z9k_connectILb0ELb1EE"}
+           "k_extend_quant": "_Z8k_extendILb0ELi1EE", "k_connect_quant": "_Z9k_connectILb0ELi1EE"}
 
 
 def assembly():
