@@ -26,7 +26,7 @@ namespace PathTracer
             public ulong Paths, ExtendRays, ShadowRays, ExtendSteps, ExtendTris, ShadowSteps, ShadowTris, StackOverflows;
             public uint ExtendLaunches, ShadeLaunches, ConnectLaunches, GenerateLaunches;
             public float MsGenerate, MsExtend, MsShade, MsConnect, MsRender, MsExtendPrimary, Reserved1, Reserved2;
-            public ulong SchedInterior, SchedLeaf, SchedRefill, SpecialRays, ExtendUniqueSteps, ExtendUniqueTris, DeviceAllocations;
+            public ulong SchedInterior, SchedLeaf, SchedRefill, SpecialRays, ExtendUniqueSteps, ExtendUniqueTris, ShadowOccluded, DeviceAllocations;
         }
 
         // pt_instance: a mesh placed by a System.Numerics.Matrix4x4 (row vectors, translation in M41..M43), 72 bytes

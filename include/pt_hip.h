@@ -100,6 +100,7 @@ typedef struct pt_stats {
     /* extend stage, traversal_stats only: node records / triangle records fetched, counting the lanes of one wave instruction
      * that ask for the same record once (the vector memory pipeline serves them together): what the stage's loads cost */
     uint64_t extend_unique_steps, extend_unique_tris;
+    uint64_t shadow_occluded;    /* shadow rays that found an occluder (traversal_stats) */
     uint64_t device_allocations; /* hipMalloc calls the library has made in this process so far (all contexts): unchanged across a
                                    call means the call allocated no device memory */
 } pt_stats;

@@ -33,7 +33,7 @@ class pt_stats(C.Structure):
                 ("ms_render", C.c_float), ("ms_extend_primary", C.c_float), ("reserved", C.c_float * 2),
                 ("sched_interior", C.c_uint64), ("sched_leaf", C.c_uint64), ("sched_refill", C.c_uint64),
                 ("special_rays", C.c_uint64), ("extend_unique_steps", C.c_uint64), ("extend_unique_tris", C.c_uint64),
-                ("device_allocations", C.c_uint64)]
+                ("shadow_occluded", C.c_uint64), ("device_allocations", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n not in ("reserved", "reserved0", "struct_size")}

@@ -1570,7 +1570,7 @@ static int gatherStats(pt_ctx* c, pt_stats* out) {
             total.extend_steps += s.extend_steps; total.extend_tris += s.extend_tris; total.shadow_steps += s.shadow_steps; total.shadow_tris += s.shadow_tris;
             total.stack_overflows += s.stack_overflows; total.sched_interior += s.sched_interior; total.sched_leaf += s.sched_leaf;
             total.sched_refill += s.sched_refill; total.special_rays += s.special_rays;
-            total.extend_unique_steps += s.extend_unique_steps; total.extend_unique_tris += s.extend_unique_tris;
+            total.extend_unique_steps += s.extend_unique_steps; total.extend_unique_tris += s.extend_unique_tris; total.shadow_occluded += s.shadow_occluded;
             total.ms_generate = std::max(total.ms_generate, s.ms_generate); total.ms_extend = std::max(total.ms_extend, s.ms_extend);
             total.ms_shade = std::max(total.ms_shade, s.ms_shade); total.ms_connect = std::max(total.ms_connect, s.ms_connect);
             total.ms_render = std::max(total.ms_render, s.ms_render); total.ms_extend_primary = std::max(total.ms_extend_primary, s.ms_extend_primary);
@@ -1597,6 +1597,7 @@ static int gatherStats(pt_ctx* c, pt_stats* out) {
     s.special_rays = ctl.special_rays;
     s.extend_unique_steps = ctl.unique_steps;
     s.extend_unique_tris = ctl.unique_tris;
+    s.shadow_occluded = ctl.shadow_occluded;
     s.device_allocations = ptAllocCount().load(std::memory_order_relaxed);
     *out = s;
     return PT_OK;

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_W
     src.o = q.o[cur];
     src.d = q.d[cur];
     src.hit = q.hit;
-    uint32_t sched[5] = {0, 0, 0, 0, 0};
+    uint32_t sched[6] = {0, 0, 0, 0, 0, 0};
     traverseWave<false, STATS, MODE>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
     if (STATS) {
         waveAdd64(&ctl->extend_steps, steps);
@@ -191,11 +191,12 @@ __global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_W
     src.sd = q.sd;
     src.sc = q.sc;
     src.plane = q.plane;
-    uint32_t sched[5] = {0, 0, 0, 0, 0};
+    uint32_t sched[6] = {0, 0, 0, 0, 0, 0};
     traverseWave<true, STATS, MODE>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
     if (STATS) {
         waveAdd64(&ctl->shadow_steps, steps);
         waveAdd64(&ctl->shadow_tris, tris);
+        if (laneId() == 0) atomicAdd(&ctl->shadow_occluded, (unsigned long long)sched[5]);
     }
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
 }
@@ -553,7 +554,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
     unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
     uint32_t steps = 0, tris = 0, overflow = 0;
-    uint32_t sched[5] = {0, 0, 0, 0, 0};
+    uint32_t sched[6] = {0, 0, 0, 0, 0, 0};
     // every wave traces its own 64 rays and never refills: the threshold is not used
     traverseWave<ANYHIT, false, MODE>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, 64u, &ctl->special_rays);
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
