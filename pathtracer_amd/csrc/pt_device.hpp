@@ -122,6 +122,7 @@ struct Ctl {
     unsigned long long sched_interior, sched_leaf, sched_refill;   // wave iterations by kind, extend stage, instrumented builds
     unsigned long long special_rays;                               // rays that took the two-wide, NaN-rejecting walk
     unsigned long long unique_steps, unique_tris;                  // extend stage, instrumented builds: DISTINCT records fetched per wave instruction, summed
+    unsigned long long shadow_occluded;                            // connect stage, instrumented builds: shadow rays that found an occluder
 };
 
 // ------------------------------------------------ deterministic elementary fns
@@ -444,7 +445,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                                              uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched, uint32_t refillMin,
                                              unsigned long long* specialRays) {
     // sched[0..2] (STATS builds): wave iterations spent on interior steps, leaf steps, retire/refill; sched[3..4]: distinct quad
-    // records / triangles fetched per wave instruction, summed (wave-uniform counts)
+    // records / triangles fetched per wave instruction, summed (wave-uniform counts); sched[5]: any-hit rays that ended occluded
     constexpr bool QUANT = MODE == PT_WALK_QUANT, INST = MODE == PT_WALK_INST;
     const uint32_t lane = laneId();
     const uint32_t totalWaves = gridDim.x * (blockDim.x / PT_WAVE);
@@ -558,6 +559,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             const bool moreRays = !(exhausted && rangeLo == rangeHi);
             if (nActive == 0u || (moreRays && 64u - nActive >= refillMin)) {
                 if (STATS) sched[2]++;
+                if (STATS && ANYHIT) sched[5] += (uint32_t)__popcll(__ballot(rayIdx != PT_NO_RAY && cur == 0u && occluded));
                 if (rayIdx != PT_NO_RAY && cur == 0u) {
                     HitRec h;
                     h.t = best; h.tri = bestTri; h.u = bu; h.v = bv;
