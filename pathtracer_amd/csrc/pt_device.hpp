@@ -417,6 +417,22 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 #define PT_ENTER_BATCH 8     // INST: lanes waiting to enter an instance that make the wave run an enter phase
 #endif
 #define PT_NO_RAY 0xFFFFFFFFu
+// The waves of a block share a pool of parked rays in LDS.  A wave whose lanes have thinned out hands its remaining rays
+// to the pool and starts again with 64 fresh ones (which walk the top of the tree together); a thinned-out wave that finds
+// enough parked rays takes them instead and runs full.  A ray's state is four 16-byte words and PT_POOL_STACK stack entries;
+// rays with a deeper stack, or in the middle of a leaf, stay where they are.  One wave at a time works on the pool (a lock it
+// tries once and never waits for), nobody ever waits for a ray to arrive, and a wave parks rays only while it has fresh ones
+// to go on with, so the last wave alive finds the pool's remainder when it runs out of work.
+#ifndef PT_POOL_SLOTS
+#define PT_POOL_SLOTS 64
+#endif
+#ifndef PT_POOL_STACK
+#define PT_POOL_STACK 8
+#endif
+#ifndef PT_POOL_MIN
+#define PT_POOL_MIN 20       // idle lanes at which a wave turns to the pool
+#endif
+#define PT_POOL_WORDS (4 + 4 * 4 * PT_POOL_SLOTS + 2 * PT_POOL_STACK * PT_POOL_SLOTS)   // 32-bit words of LDS per block: lock, count, pad; state; stacks
 #ifndef PT_GRAB_LARGE
 #define PT_GRAB_LARGE 256u
 #endif
@@ -440,10 +456,12 @@ __device__ __forceinline__ bool triangleTest(float4 q0, float4 q1, float4 q2, f3
 #define PT_MARK(name)
 #endif
 
-template <bool ANYHIT, bool STATS, int MODE, class Source>
+template <bool ANYHIT, bool STATS, int MODE, bool POOL, class Source>
 __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uint32_t* cursor, uint2* lstack, unsigned long long* leafq, const Source& src,
                                              uint32_t* nsteps, uint32_t* ntris, uint32_t* overflow, uint32_t* sched, uint32_t refillMin,
-                                             unsigned long long* specialRays) {
+                                             unsigned long long* specialRays, uint32_t* pool = nullptr) {
+    static_assert(!(POOL && MODE == PT_WALK_INST), "the pool does not carry the instanced walk's second ray");
+    static_assert(PT_POOL_STACK <= PT_STACK_LDS, "parked stacks are copied from the LDS part of a lane's stack");
     // sched[0..2] (STATS builds): wave iterations spent on interior steps, leaf steps, retire/refill; sched[3..4]: distinct quad
     // records / triangles fetched per wave instruction, summed (wave-uniform counts); sched[5]: any-hit rays that ended occluded
     constexpr bool QUANT = MODE == PT_WALK_QUANT, INST = MODE == PT_WALK_INST;
@@ -551,13 +569,24 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
         }
     };
 
+    // POOL: the block's parked rays (see PT_POOL_SLOTS): word 0 lock, word 1 count, then four 16-byte state words per slot
+    // ([word][slot]) and PT_POOL_STACK stack entries per slot ([entry][slot])
+    volatile uint32_t* const poolCtl = pool;
+    uint4* const poolState = (uint4*)(pool + 4);
+    uint2* const poolStack = (uint2*)(pool + 4 + 16 * PT_POOL_SLOTS);
+    uint32_t breakAt = POOL ? (uint32_t)PT_POOL_MIN : refillMin;   // idle lanes at which the stepping loops hand over to the block below
     for (;;) {
         // ---- retire finished rays and hand the idle lanes the next rays: when nothing is in flight, or when
-        //      refillMin lanes are idle and rays remain to be handed out
+        //      refillMin lanes are idle and rays remain to be handed out; POOL: also when the wave has thinned out
+        //      enough to trade rays with the block's pool
         {
-            const uint32_t nActive = (uint32_t)__popcll(__ballot(cur != 0u));
+            const uint32_t nActive0 = (uint32_t)__popcll(__ballot(cur != 0u));
             const bool moreRays = !(exhausted && rangeLo == rangeHi);
-            if (nActive == 0u || (moreRays && 64u - nActive >= refillMin)) {
+            uint32_t parked = 0;
+            if (POOL) parked = poolCtl[1];
+            bool service = nActive0 == 0u || (moreRays && 64u - nActive0 >= refillMin);
+            if (POOL) service = service || (64u - nActive0 >= breakAt && (moreRays || parked != 0u));
+            if (service) {
                 if (STATS) sched[2]++;
                 if (STATS && ANYHIT) sched[5] += (uint32_t)__popcll(__ballot(rayIdx != PT_NO_RAY && cur == 0u && occluded));
                 if (rayIdx != PT_NO_RAY && cur == 0u) {
@@ -568,7 +597,80 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     src.store(rayIdx, h, occluded);
                     rayIdx = PT_NO_RAY;
                 }
-                if (rangeLo == rangeHi && !exhausted) {
+                uint32_t nActive = nActive0;
+                if (POOL && (parked != 0u || (moreRays && nActive0 != 0u))) {
+                    uint32_t locked = 0;
+                    if (lane == 0u) locked = atomicCAS((uint32_t*)pool, 0u, 1u) == 0u ? 1u : 0u;
+                    locked = (uint32_t)__builtin_amdgcn_readfirstlane((int)locked);
+                    if (locked != 0u) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const uint32_t count = poolCtl[1];
+                        const uint32_t nIdle = 64u - nActive0;
+                        if (count != 0u && (count >= nIdle || !moreRays)) {
+                            // take: the idle lanes pick up the rays parked last
+                            const uint32_t take = count < nIdle ? count : nIdle;
+                            const unsigned long long idle = __ballot(rayIdx == PT_NO_RAY);
+                            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                            if (rayIdx == PT_NO_RAY && rank < take) {
+                                const uint32_t slot = count - 1u - rank;
+                                const uint4 A = poolState[slot], B = poolState[PT_POOL_SLOTS + slot], C = poolState[2 * PT_POOL_SLOTS + slot],
+                                            D = poolState[3 * PT_POOL_SLOTS + slot];
+                                o = mk3(__uint_as_float(A.x), __uint_as_float(A.y), __uint_as_float(A.z));
+                                rayIdx = A.w;
+                                d = mk3(__uint_as_float(B.x), __uint_as_float(B.y), __uint_as_float(B.z));
+                                enter(B.w);
+                                inv = mk3(__uint_as_float(C.x), __uint_as_float(C.y), __uint_as_float(C.z));
+                                sp = (int)(C.w & 0xffu);
+                                special = (C.w & 0x100u) != 0u;
+                                occluded = false;
+                                if (ANYHIT) {
+                                    tlimit = __uint_as_float(D.x);
+                                    best = tlimit;
+                                } else {
+                                    tlimit = PT_INF;
+                                    best = __uint_as_float(D.x); bu = __uint_as_float(D.y); bv = __uint_as_float(D.z); bestTri = (int32_t)D.w;
+                                }
+                                if (QUANT) {
+                                    qa = mk3(sc.grid_cell[0] * inv.x, sc.grid_cell[1] * inv.y, sc.grid_cell[2] * inv.z);
+                                    qb = mk3((sc.grid_min[0] - o.x) * inv.x, (sc.grid_min[1] - o.y) * inv.y, (sc.grid_min[2] - o.z) * inv.z);
+                                }
+#pragma unroll
+                                for (int e = 0; e < PT_POOL_STACK; e++)
+                                    if (e < sp) mystack[e * PT_WAVE] = poolStack[e * PT_POOL_SLOTS + slot];
+                            }
+                            if (lane == 0u) poolCtl[1] = count - take;
+                            nActive += take;
+                        } else if (moreRays && nActive0 != 0u) {
+                            // park: every ray that can travel, if the pool has room for all of them
+                            const bool parkable = cur != 0u && sp <= PT_POOL_STACK && !((int32_t)cur < 0 && leafEnd != 0);
+                            const unsigned long long pm = __ballot(parkable);
+                            const uint32_t np = (uint32_t)__popcll(pm);
+                            if (np != 0u && count + np <= (uint32_t)PT_POOL_SLOTS) {
+                                if (parkable) {
+                                    const uint32_t slot = count + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                                    poolState[slot] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), rayIdx);
+                                    poolState[PT_POOL_SLOTS + slot] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), cur);
+                                    poolState[2 * PT_POOL_SLOTS + slot] =
+                                        make_uint4(__float_as_uint(inv.x), __float_as_uint(inv.y), __float_as_uint(inv.z), (uint32_t)sp | (special ? 0x100u : 0u));
+                                    poolState[3 * PT_POOL_SLOTS + slot] = ANYHIT ? make_uint4(__float_as_uint(tlimit), 0u, 0u, 0u)
+                                                                                 : make_uint4(__float_as_uint(best), __float_as_uint(bu), __float_as_uint(bv), (uint32_t)bestTri);
+#pragma unroll
+                                    for (int e = 0; e < PT_POOL_STACK; e++)
+                                        if (e < sp) poolStack[e * PT_POOL_SLOTS + slot] = mystack[e * PT_WAVE];
+                                    rayIdx = PT_NO_RAY;
+                                    cur = 0u;
+                                    sp = 0;
+                                }
+                                if (lane == 0u) poolCtl[1] = count + np;
+                                nActive -= np;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0u) poolCtl[0] = 0u;
+                    }
+                }
+                const bool fresh = nActive == 0u || (moreRays && 64u - nActive >= refillMin);
+                if (fresh && rangeLo == rangeHi && !exhausted) {
                     uint32_t got = 0;
                     if (lane == 0) got = atomicAdd(cursor, grab);
                     got = __shfl(got, 0);
@@ -576,8 +678,12 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                     if (lo >= n) exhausted = true;
                     else { rangeLo = lo; rangeHi = lo + grab < n ? lo + grab : n; }
                 }
-                const uint32_t avail = rangeHi - rangeLo;
-                if (avail == 0u && nActive == 0u) break;   // nothing in flight and nothing left to hand out
+                const uint32_t avail = fresh ? rangeHi - rangeLo : 0u;
+                if (fresh && avail == 0u && nActive == 0u) {   // nothing in flight and nothing left to hand out
+                    if (!POOL) break;
+                    if (poolCtl[1] == 0u) break;               // (rays that a wave parks from now on are that wave's to pick up)
+                    __builtin_amdgcn_s_sleep(2);
+                }
                 const unsigned long long idleMask = __ballot(rayIdx == PT_NO_RAY);
                 const uint32_t rank = (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
                 if (rayIdx == PT_NO_RAY && rank < avail) {
@@ -623,16 +729,24 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                 }
                 const uint32_t nIdle = (uint32_t)__popcll(idleMask);
                 rangeLo += nIdle < avail ? nIdle : avail;
+                if (POOL) {
+                    // the next visit: once enough lanes are idle to trade with the pool; if this visit left that many idle
+                    // (nothing to take, no room to park), after eight more have finished
+                    const uint32_t idleNow = 64u - (uint32_t)__popcll(__ballot(rayIdx != PT_NO_RAY));
+                    breakAt = idleNow < (uint32_t)PT_POOL_MIN ? (uint32_t)PT_POOL_MIN : idleNow + 8u;
+                }
             }
         }
-        const bool refillable = !(exhausted && rangeLo == rangeHi);
+        // (the pool's count is read afresh here and again at the top of the loop: a wave that leaves the stepping loops because the
+        // pool had rays either trades with it there, which moves breakAt beyond its idle lanes, or comes back here and finds it empty)
+        const bool refillable = !(exhausted && rangeLo == rangeHi) || (POOL && poolCtl[1] != 0u);
         // ---- interior steps, for as long as that is the wave's kind of work
         for (;;) {
             const unsigned long long interiorMask = __ballot((int32_t)cur > 0);
             const uint32_t nEnter = INST ? (uint32_t)__popcll(__ballot(atInstance())) : 0u;
             const uint32_t nLeaf = (uint32_t)__popcll(__ballot((int32_t)cur < 0)) - nEnter;
             if (interiorMask == 0ull || nLeaf >= PT_LEAF_BATCH || nEnter >= PT_ENTER_BATCH) break;
-            if (refillable && 64u - (uint32_t)__popcll(interiorMask) - nLeaf - nEnter >= refillMin) break;
+            if (refillable && 64u - (uint32_t)__popcll(interiorMask) - nLeaf - nEnter >= breakAt) break;
             if (STATS) sched[0]++;
             PT_MARK("interior_begin");
             if (STATS) {
@@ -770,7 +884,7 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
             const uint32_t nLeaf = (uint32_t)__popcll(leafMask);
             const uint32_t nInterior = (uint32_t)__popcll(__ballot((int32_t)cur > 0));
             if (nInterior != 0u && nLeaf < PT_LEAF_BATCH) break;
-            if (refillable && 64u - nInterior - nLeaf - (INST ? (uint32_t)__popcll(__ballot(atInstance())) : 0u) >= refillMin) break;
+            if (refillable && 64u - nInterior - nLeaf - (INST ? (uint32_t)__popcll(__ballot(atInstance())) : 0u) >= breakAt) break;
             if (STATS) sched[1]++;
             PT_MARK("leaf_begin");
             unsigned long long* const resKey = leafq;                       // [64] best (distance bits, triangle) per owner

@@ -27,6 +27,9 @@ __device__ __forceinline__ void ntStore(float4* p, float4 v) {
 #ifndef PT_TRAVERSE_WAVES
 #define PT_TRAVERSE_WAVES 5   // minimum waves per SIMD the traversal kernels are compiled for (caps their VGPRs)
 #endif
+#ifndef PT_POOL
+#define PT_POOL 0             // whether the waves of a traversal block trade thinned-out rays through LDS (see PT_POOL_SLOTS)
+#endif
 
 struct RenderParams {
     int32_t width, height;
@@ -122,11 +125,17 @@ struct ExtendSource {
 
 // the instanced walk carries a second ray (the one in the mesh's space) and is compiled for one wave per SIMD less
 template <bool STATS, int MODE>
-__global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_WAVES - 1 : (MODE == PT_WALK_QUANT ? PT_TRAVERSE_WAVES + 1 : PT_TRAVERSE_WAVES)) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
+__global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_WAVES - 1 : ((MODE == PT_WALK_QUANT || PT_POOL != 0) ? PT_TRAVERSE_WAVES + 1 : PT_TRAVERSE_WAVES)) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
     unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
+    constexpr bool POOL = PT_POOL != 0 && MODE != PT_WALK_INST;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_pool[POOL ? PT_POOL_WORDS : 4];
+    if (POOL) {
+        if (threadIdx.x < 4) lds_pool[threadIdx.x] = 0u;
+        __syncthreads();
+    }
     const uint32_t n = ctl->count[cur];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // counters of the stages that follow this launch
@@ -140,7 +149,7 @@ __global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_W
     src.d = q.d[cur];
     src.hit = q.hit;
     uint32_t sched[6] = {0, 0, 0, 0, 0, 0};
-    traverseWave<false, STATS, MODE>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
+    traverseWave<false, STATS, MODE, POOL>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays, lds_pool);
     if (STATS) {
         waveAdd64(&ctl->extend_steps, steps);
         waveAdd64(&ctl->extend_tris, tris);
@@ -178,11 +187,17 @@ struct ConnectSource {
 };
 
 template <bool STATS, int MODE>
-__global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_WAVES - 1 : PT_TRAVERSE_WAVES) k_connect(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
+__global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_WAVES - 1 : (PT_POOL != 0 ? PT_TRAVERSE_WAVES + 1 : PT_TRAVERSE_WAVES)) k_connect(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
     unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
+    constexpr bool POOL = PT_POOL != 0 && MODE != PT_WALK_INST;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_pool[POOL ? PT_POOL_WORDS : 4];
+    if (POOL) {
+        if (threadIdx.x < 4) lds_pool[threadIdx.x] = 0u;
+        __syncthreads();
+    }
     const uint32_t n = ctl->shadow_count[cur];
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctl->shadow_rays, (unsigned long long)n);
     uint32_t steps = 0, tris = 0, overflow = 0;
@@ -192,7 +207,7 @@ __global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_W
     src.sc = q.sc;
     src.plane = q.plane;
     uint32_t sched[6] = {0, 0, 0, 0, 0, 0};
-    traverseWave<true, STATS, MODE>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays);
+    traverseWave<true, STATS, MODE, POOL>(sc, n, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays, lds_pool);
     if (STATS) {
         waveAdd64(&ctl->shadow_steps, steps);
         waveAdd64(&ctl->shadow_tris, tris);
@@ -556,7 +571,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace(DevScene sc, TraceSource src
     uint32_t steps = 0, tris = 0, overflow = 0;
     uint32_t sched[6] = {0, 0, 0, 0, 0, 0};
     // every wave traces its own 64 rays and never refills: the threshold is not used
-    traverseWave<ANYHIT, false, MODE>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, 64u, &ctl->special_rays);
+    traverseWave<ANYHIT, false, MODE, false>(sc, (uint32_t)n, nullptr, lstack, leafq, src, &steps, &tris, &overflow, sched, 64u, &ctl->special_rays);
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
 }
 

@@ -16,7 +16,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 def main():
     want = sys.argv[1:] or ["k_extend", "k_connect", "k_shade", "k_generate", "k_trace"]
-    lib = os.path.join(ROOT, "pathtracer_amd", "libpt_hip.so")
+    lib = os.path.join(ROOT, "pathtracer_amd", os.environ.get("PT_HIP_LIB", "libpt_hip.so"))   # PT_HIP_LIB: another build of the library
     with tempfile.TemporaryDirectory() as tmp:
         fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "co.o")
         subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib], check=True)
