@@ -107,6 +107,9 @@ struct pt_ctx {
     // triangles); trees that stay in L2 are bound by instruction issue and keep the exact 128-byte records.  quant_mode: 0 never,
     // 1 whenever the records exist, 2 for large trees (PT_OPT_QUANTIZED).
     bool quant_ok = false;
+    // the traversal addresses an exact quad record with a 32-bit byte offset: beyond 4 GB of them (about 100M triangles) only the
+    // quantised records are walked, whatever PT_OPT_QUANTIZED says
+    bool exact_ok = true;
     int quant_mode = 2;
     // The scene as instances of meshes (pt_build_scene_instanced): walked only when the host asks (PT_OPT_INSTANCED), because hits
     // the flattened walk drops for missing their leaf's box are found by this one.
@@ -620,7 +623,7 @@ int pt_reset_accumulation(pt_ctx* c) {
 
 // The wide pass over the queue, then the two-wide pass over the rays it set aside (normally none).
 // whether the traversal kernels walk the quantised records of the installed scene
-static bool useQuant(const pt_ctx* c) { return c->quant_ok && (c->quant_mode == 1 || (c->quant_mode == 2 && c->large_tree)); }
+static bool useQuant(const pt_ctx* c) { return c->quant_ok && (c->quant_mode == 1 || (c->quant_mode == 2 && c->large_tree) || !c->exact_ok); }
 
 // which records the traversal kernels walk for the installed scene
 static int walkMode(const pt_ctx* c) {
@@ -1224,6 +1227,7 @@ static void adoptScene(pt_ctx* c, SceneWork& w, uint32_t n, uint32_t nn) {
     ptrepack::gridOf(w.root.mn, w.root.mx, &grid);   // the expression k_qrecords evaluated on the device
     for (int k = 0; k < 3; k++) { sc.grid_min[k] = grid.mn[k]; sc.grid_cell[k] = grid.cell[k]; sc.grid_mid[k] = grid.mid[k]; sc.grid_reach[k] = grid.reach[k]; }
     c->quant_ok = n > 0 && w.qbad == 0 && (w.nQuads == 0 || c->d_qquads != nullptr) && c->d_gate != nullptr;
+    c->exact_ok = (size_t)w.nQuads * 128 < ((size_t)1 << 32);
     sc.iquads = (const float4*)c->d_iquads;
     sc.ibig = (const uint2*)c->d_ibig;
     sc.itris = (const float4*)c->d_itris;
@@ -1445,6 +1449,8 @@ static int impl_build_scene(pt_ctx* c, const void* materials, int32_t n_mat, con
     if (nodes_out) TRY(hipMemcpyAsync(nodes_out, w.d_nodes, (size_t)nn * 32, hipMemcpyDeviceToHost, c->stream));
     TRY(hipGetLastError());
     TRY(hipStreamSynchronize(c->stream));
+    if ((size_t)w.nQuads * 128 >= ((size_t)1 << 32) && w.qbad != 0)
+        FAIL(c, PT_E_INVALID_ARG, "%u quad records exceed 4 GB and the scene's extent does not admit the quantised records", w.nQuads);
     if (build_ms) {
         *build_ms = 0.0f;
         if (w.ea && w.eb) (void)hipEventElapsedTime(build_ms, w.ea, w.eb);
@@ -1527,6 +1533,8 @@ static int uploadOne(pt_ctx* c, const void* materials, int32_t n_mat, const void
     if (rc != PT_OK) return rc;
     TRY(hipGetLastError());
     TRY(hipStreamSynchronize(c->stream));
+    if ((size_t)w.nQuads * 128 >= ((size_t)1 << 32) && w.qbad != 0)
+        FAIL(c, PT_E_INVALID_ARG, "%u quad records exceed 4 GB and the scene's extent does not admit the quantised records", w.nQuads);
     adoptScene(c, w, n, nn);
     return PT_OK;
 }

@@ -796,14 +796,29 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                         PT_QUANT_CHILD(k3, w0.y >> 16, w0.w >> 16, w1.y >> 16, w1.w >> 16, w2.y >> 16, w2.w >> 16, 3u)
 #undef PT_QUANT_CHILD
                     } else {
-                        const float4* p = (INST ? sc.iquads : sc.quads) + 8 * (size_t)(cur - 1u);
-                        const float4 mnx = p[0], mny = p[1], mnz = p[2], mxx = p[3], mxy = p[4], mxz = p[5];
-                        const float4 eb = p[6];
+                        // Box.cs:51-79 takes min and max of each axis' two plane distances.  (plane - o) * (1/d) is monotone in the plane
+                        // (subtraction and multiplication round monotonically, the ray cannot produce NaN here), so for d > 0 the smaller
+                        // distance is the min plane's and for d < 0 the max plane's: each lane fetches the column that is its near plane
+                        // and the one that is its far plane (columns 48 bytes apart) and the twelve pairwise min / max of a step fall away.
+                        // The entry distance is then the largest near distance, the exit distance the smallest far one: the same values.
+                        const char* const qbase = (const char*)(INST ? sc.iquads : sc.quads);
+                        const uint32_t rec = (cur - 1u) << 7;   // the host installs exact records only while they stay below 4 GB
+                        const f3& iv = INST ? invc : inv;
+                        const f3& ov = INST ? oc : o;
+                        // (all-ones masks from the sign bits of the reciprocals pick between the record's offset and that plus 48)
+                        const int32_t mx = __float_as_int(iv.x) >> 31, my = __float_as_int(iv.y) >> 31, mz = __float_as_int(iv.z) >> 31;
+                        const uint32_t rec48 = rec + 48u;
+#define PT_PICK(M, A, B) (((uint32_t)(M) & (A)) | (~(uint32_t)(M) & (B)))   /* one v_bfi_b32 */
+                        const float4 nx = *(const float4*)(qbase + (size_t)PT_PICK(mx, rec48, rec)), fx = *(const float4*)(qbase + (size_t)PT_PICK(mx, rec, rec48));
+                        const float4 ny = *(const float4*)(qbase + (size_t)PT_PICK(my, rec48, rec) + 16), fy = *(const float4*)(qbase + (size_t)PT_PICK(my, rec, rec48) + 16);
+                        const float4 nz = *(const float4*)(qbase + (size_t)PT_PICK(mz, rec48, rec) + 32), fz = *(const float4*)(qbase + (size_t)PT_PICK(mz, rec, rec48) + 32);
+#undef PT_PICK
+                        const float4 eb = *(const float4*)(qbase + (size_t)rec + 96);
                         e0 = __float_as_uint(eb.x); e1 = __float_as_uint(eb.y); e2 = __float_as_uint(eb.z); e3 = __float_as_uint(eb.w);
 #define PT_QUAD_CHILD(K, C, SLOT)                                                                             \
                     {                                                                                          \
-                        float tm, tx;                                                                          \
-                        slabRange(mnx.C, mny.C, mnz.C, mxx.C, mxy.C, mxz.C, INST ? oc : o, INST ? invc : inv, &tm, &tx); \
+                        const float tm = fmaxf(fmaxf((nx.C - ov.x) * iv.x, (ny.C - ov.y) * iv.y), (nz.C - ov.z) * iv.z); \
+                        const float tx = fminf(fminf((fx.C - ov.x) * iv.x, (fy.C - ov.y) * iv.y), (fz.C - ov.z) * iv.z); \
                         PT_QUAD_KEY(K, tm, tx, SLOT)                                                           \
                     }
                         PT_QUAD_CHILD(k0, x, 0u)
