@@ -780,20 +780,24 @@ __device__ __forceinline__ void traverseWave(const DevScene& sc, uint32_t n, uin
                         const uint4* p = sc.qquads + 4 * (size_t)(cur - 1u);
                         const uint4 w0 = p[0], w1 = p[1], w2 = p[2], we = p[3];
                         e0 = we.x; e1 = we.y; e2 = we.z; e3 = we.w;
-                        // distances of the six grid planes of a child: fma(cell number, cell / d, (grid_min - o) / d), see rayOffGrid
-#define PT_QUANT_CHILD(K, LX, LY, LZ, HX, HY, HZ, SLOT)                                                       \
+                        // distances of the six grid planes of a child: fma(cell number, cell / d, (grid_min - o) / d), see rayOffGrid.
+                        // The fma is monotone in the cell number, so the nearer of an axis' two planes is the low one for d > 0 and the
+                        // high one for d < 0 (as for the exact records below): the words holding the near and the far cells are picked by
+                        // the sign once per step, and the pairwise min / max per child fall away.
+                        const bool ngx = qa.x < 0.0f, ngy = qa.y < 0.0f, ngz = qa.z < 0.0f;
+                        const uint32_t nxa = ngx ? w1.z : w0.x, nxb = ngx ? w1.w : w0.y, fxa = ngx ? w0.x : w1.z, fxb = ngx ? w0.y : w1.w;
+                        const uint32_t nya = ngy ? w2.x : w0.z, nyb = ngy ? w2.y : w0.w, fya = ngy ? w0.z : w2.x, fyb = ngy ? w0.w : w2.y;
+                        const uint32_t nza = ngz ? w2.z : w1.x, nzb = ngz ? w2.w : w1.y, fza = ngz ? w1.x : w2.z, fzb = ngz ? w1.y : w2.w;
+#define PT_QUANT_CHILD(K, NX, NY, NZ, FX, FY, FZ, SLOT)                                                       \
                     {                                                                                          \
-                        const float t1 = fmaf((float)(LX), qa.x, qb.x), t2 = fmaf((float)(HX), qa.x, qb.x);    \
-                        const float t3 = fmaf((float)(LY), qa.y, qb.y), t4 = fmaf((float)(HY), qa.y, qb.y);    \
-                        const float t5 = fmaf((float)(LZ), qa.z, qb.z), t6 = fmaf((float)(HZ), qa.z, qb.z);    \
-                        const float tm = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));            \
-                        const float tx = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));            \
+                        const float tm = fmaxf(fmaxf(fmaf((float)(NX), qa.x, qb.x), fmaf((float)(NY), qa.y, qb.y)), fmaf((float)(NZ), qa.z, qb.z)); \
+                        const float tx = fminf(fminf(fmaf((float)(FX), qa.x, qb.x), fmaf((float)(FY), qa.y, qb.y)), fmaf((float)(FZ), qa.z, qb.z)); \
                         PT_QUAD_KEY(K, tm, tx, SLOT)                                                           \
                     }
-                        PT_QUANT_CHILD(k0, w0.x & 0xffffu, w0.z & 0xffffu, w1.x & 0xffffu, w1.z & 0xffffu, w2.x & 0xffffu, w2.z & 0xffffu, 0u)
-                        PT_QUANT_CHILD(k1, w0.x >> 16, w0.z >> 16, w1.x >> 16, w1.z >> 16, w2.x >> 16, w2.z >> 16, 1u)
-                        PT_QUANT_CHILD(k2, w0.y & 0xffffu, w0.w & 0xffffu, w1.y & 0xffffu, w1.w & 0xffffu, w2.y & 0xffffu, w2.w & 0xffffu, 2u)
-                        PT_QUANT_CHILD(k3, w0.y >> 16, w0.w >> 16, w1.y >> 16, w1.w >> 16, w2.y >> 16, w2.w >> 16, 3u)
+                        PT_QUANT_CHILD(k0, nxa & 0xffffu, nya & 0xffffu, nza & 0xffffu, fxa & 0xffffu, fya & 0xffffu, fza & 0xffffu, 0u)
+                        PT_QUANT_CHILD(k1, nxa >> 16, nya >> 16, nza >> 16, fxa >> 16, fya >> 16, fza >> 16, 1u)
+                        PT_QUANT_CHILD(k2, nxb & 0xffffu, nyb & 0xffffu, nzb & 0xffffu, fxb & 0xffffu, fyb & 0xffffu, fzb & 0xffffu, 2u)
+                        PT_QUANT_CHILD(k3, nxb >> 16, nyb >> 16, nzb >> 16, fxb >> 16, fyb >> 16, fzb >> 16, 3u)
 #undef PT_QUANT_CHILD
                     } else {
                         // Box.cs:51-79 takes min and max of each axis' two plane distances.  (plane - o) * (1/d) is monotone in the plane
