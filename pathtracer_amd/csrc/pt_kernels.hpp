@@ -125,7 +125,7 @@ struct ExtendSource {
 
 // the instanced walk carries a second ray (the one in the mesh's space) and is compiled for one wave per SIMD less
 template <bool STATS, int MODE>
-__global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_WAVES - 1 : ((MODE == PT_WALK_QUANT || PT_POOL != 0) ? PT_TRAVERSE_WAVES + 1 : PT_TRAVERSE_WAVES)) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
+__global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_WAVES : ((MODE == PT_WALK_QUANT || PT_POOL != 0) ? PT_TRAVERSE_WAVES + 1 : PT_TRAVERSE_WAVES)) k_extend(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
@@ -187,7 +187,7 @@ struct ConnectSource {
 };
 
 template <bool STATS, int MODE>
-__global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_WAVES - 1 : (PT_POOL != 0 ? PT_TRAVERSE_WAVES + 1 : PT_TRAVERSE_WAVES)) k_connect(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
+__global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_WAVES : (PT_POOL != 0 ? PT_TRAVERSE_WAVES + 1 : PT_TRAVERSE_WAVES)) k_connect(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin) {
     __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
     __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
     uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);

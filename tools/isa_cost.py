@@ -32,7 +32,7 @@ def assembly():
     hipcc = "hipcc" if subprocess.run(["which", "hipcc"], capture_output=True).returncode == 0 else "/opt/rocm/bin/hipcc"
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "marks.s")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DPT_ISA_MARKS", "--cuda-device-only", "-S",
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-DPT_ISA_MARKS", "--cuda-device-only", "-S",
                "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "pathtracer_amd", "csrc"), "-o", out,
                os.path.join(ROOT, "pathtracer_amd", "csrc", "pt_api.hip")]
         subprocess.run(cmd, check=True, capture_output=True)
@@ -145,7 +145,7 @@ def measure():
         succ = successors(blocks, labels)
         out[kernel] = {"interior_iteration": body_cost(blocks, succ, "interior"), "leaf_phase": body_cost(blocks, succ, "leaf")}
     out["method"] = ("instructions of every basic block on a path between the PT_MARK begin/end comments of the -DPT_ISA_MARKS build "
-                     "(hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -S); inner loops counted once; tools/isa_cost.py")
+                     "(hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -S); inner loops counted once; tools/isa_cost.py")
     return out
 
 
