@@ -59,6 +59,11 @@ ALG_LANEOPS_PER_TRI = 53
 # SIMD and clock, 4 SIMDs x 256 CUs at 2.4 GHz.  Not the 157 TFLOP/s headline: that counts packed two-wide FMAs, and this path
 # may neither fuse (bit-exactness with the C# arithmetic) nor pack (one ray per lane).
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+# What the SIMDs were measured to issue with several waves resident (tools/micro/valu_rate.hip, profiles/r03_micro_valu_rate.txt):
+# float add / sub / mul / fma and the plain two-operand integer and logic instructions about one wave64 instruction per 2.5 clocks,
+# min / max / selects / compares / three-operand instructions one per 4.2 (clocks of the nominal 2.4 GHz).  isa_cost.json counts the
+# first kind apart (valu_fast), and the line reports the share of a launch's SIMD time those rates account for (issue_time_frac).
+VALU_CLOCKS_FAST, VALU_CLOCKS_FULL = 2.5, 4.2
 HBM_PEAK_GBS = 8000.0
 
 
@@ -274,6 +279,11 @@ def traversal_roofline(counted, timed, kernel_cost, n_quads, n_tris, pmc, quant=
     lane_int = counted["extend_steps"] / max(1, 64 * counted["sched_interior"])
     lane_leaf = counted["extend_tris"] / max(1, 64 * counted["sched_leaf"])
     issued = counted["sched_interior"] * i_int + counted["sched_leaf"] * i_leaf     # wave instructions, the two loops only
+    # the same instructions priced at the rates the SIMDs were measured to issue them at: the share of the launches' SIMD time they take
+    f_int, f_leaf = kernel_cost["interior_iteration"].get("valu_fast", 0), kernel_cost["leaf_phase"].get("valu_fast", 0)
+    issue_clocks = (counted["sched_interior"] * (f_int * VALU_CLOCKS_FAST + (i_int - f_int) * VALU_CLOCKS_FULL) +
+                    counted["sched_leaf"] * (f_leaf * VALU_CLOCKS_FAST + (i_leaf - f_leaf) * VALU_CLOCKS_FULL))
+    issue_time_frac = issue_clocks / max(1, counted["extend_launches"]) / (sec * 2.4e9 * 256 * 4 * gpus)
     # HBM: the bytes a launch cannot avoid moving are its ray records (32 in, 16 out) and one pass over the tree and the hot
     # triangle records; everything else the walk touches is re-use that the caches serve
     scene_bytes = (64.0 * n_quads + 64.0 * n_tris) if quant else (128.0 * n_quads + 48.0 * n_tris)
@@ -298,6 +308,9 @@ def traversal_roofline(counted, timed, kernel_cost, n_quads, n_tris, pmc, quant=
             "lane_utilisation": {"interior": lane_int, "leaf": lane_leaf,
                                  "overall": (counted["extend_steps"] * i_int + counted["extend_tris"] * i_leaf) / max(1, 64 * issued)},
             "issue_model_wave_instr_per_ray": issued / rays, "valu_busy_pmc": pmc.get("valu_busy"),
+            "issue_time_frac": issue_time_frac, "valu_fast_instr": {"interior_iteration": f_int, "leaf_phase": f_leaf},
+            "issue_time_note": "wave iterations x (fast instructions x 2.5 + the others x 4.2 clocks) over the launches' SIMD clocks: float add/sub/mul/fma and plain "
+                               "two-operand integer instructions were measured at one per 2.5 clocks per SIMD, the rest at one per 4.2 (profiles/r03_micro_valu_rate.txt)",
             # cross-check of the instruction counts: wave iterations x VALU instructions per iteration against the hardware's count of
             # the same kernel (committed PMC pass; the two loops only, so a little below 1 is expected)
             "issue_model_over_sq_insts_valu": (issued / max(1, counted["extend_launches"]) / pmc["sq_insts_valu_per_launch"]) if pmc.get("sq_insts_valu_per_launch") else None}

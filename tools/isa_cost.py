@@ -112,6 +112,16 @@ def classify(op):
     return "other"
 
 
+# Instructions measured at about one per 2.5 clocks per SIMD with several waves resident (tools/micro/valu_rate.hip,
+# profiles/r03_micro_valu_rate.txt), in their 32-bit encoding; every other vector-ALU instruction issues at about one per 4.2
+FAST = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_add_u32", "v_sub_u32", "v_subrev_u32",
+        "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_mov_b32", "v_ashrrev_i32"}
+
+
+def is_fast(op):
+    return op.endswith("_e32") and op[:-4] in FAST
+
+
 def body_cost(blocks, succ, name):
     begin = next(i for i, b in enumerate(blocks) if b and b[0] == f"; PT_MARK {name}_begin")
     end = next(i for i, b in enumerate(blocks) if b and b[0] == f"; PT_MARK {name}_end")
@@ -128,10 +138,13 @@ def body_cost(blocks, succ, name):
         for e in cold_e:
             cold |= reach(b, e, succ) & reach(e, b, pred)
     body -= cold
-    cost = {"valu": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0}
+    cost = {"valu": 0, "valu_fast": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0}
     for i in sorted(body):
         for ins in blocks[i]:
-            cost[classify(ins.split()[0])] += 1
+            op = ins.split()[0]
+            cost[classify(op)] += 1
+            if is_fast(op):
+                cost["valu_fast"] += 1     # of the "valu" count
     cost["blocks"] = len(body)
     cost["cold_blocks_left_out"] = len(cold)
     return cost
