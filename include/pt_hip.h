@@ -57,7 +57,8 @@ typedef struct pt_config {
     int32_t rng_mode;           /* 0 = reference seeding (generate.glsl:174, shade.glsl:352), 1 = decorrelated hash */
     int32_t tile_rank;          /* this context renders pixel groups g with g % tile_world == tile_rank */
     int32_t tile_world;
-    int32_t samples_per_batch;  /* samples traced concurrently; 0 = choose from the pixel count */
+    int32_t samples_per_batch;  /* samples traced concurrently; 0 = as many as give 256M paths per launch (176 bytes of device memory per path,
+                                   at most a quarter of what is free); a number bounds the memory a render call takes */
     int32_t traversal_stats;    /* 1 = count BVH steps / triangle tests (slower instrumented kernels) */
     int32_t stage_timing;       /* 1 = bracket every stage launch with events (pt_get_stats ms_*), 2 = the extend
                                    launches only (a pair of events costs about 5 us of stream time) */
