@@ -196,6 +196,8 @@ class Run:
         else:
             self.wf = pa.Wavefront(device=local_rank, nee=bool(nee), rng_mode=1, tile_rank=rank, tile_world=world,
                                    samples_per_batch=args.batch, stage_timing=1)
+        if getattr(args, "no_pipeline", False):
+            self.wf.set_option(11, 0)
         self.instanced = bool(getattr(args, "instanced", 0))
         if self.instanced:
             # the same scene, built on the GPU, with the tree over instances beside the flattened one; the kernels walk the instances
@@ -421,6 +423,7 @@ def main():
     ap.add_argument("--quant", type=int, default=2, choices=[0, 1, 2], help="node records the traversal walks: 0 exact 128-byte, 1 quantised 64-byte, 2 the library's rule")
     ap.add_argument("--instanced", action="store_true", help="walk the scene as instances of meshes (pt_build_scene_instanced + PT_OPT_INSTANCED): opt-in mode, "
                     "same hit distances, see pt_hip.h")
+    ap.add_argument("--no-pipeline", action="store_true", help="one set of streams and queues (PT_OPT_PIPELINE_CALLS = 0): consecutive frames do not overlap")
     ap.add_argument("--in-process", action="store_true", help="N GPUs behind ONE context in this one process (pt_config.device_count = N: tile sharding and the "
                     "RCCL gather inside libpt_hip.so) instead of one process per GPU")
     args = ap.parse_args()

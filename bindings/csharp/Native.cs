@@ -39,7 +39,8 @@ namespace PathTracer
 
         // PT_OPT_* keys of pt_set_option
         public const int OptNee = 1, OptRngMode = 2, OptTraversalStats = 3, OptStageTiming = 4, OptSamplesPerBatch = 5,
-                         OptTraverseBlocksPerCu = 6, OptRefillPrimary = 7, OptRefillBounce = 8, OptQuantized = 9, OptInstanced = 10;
+                         OptTraverseBlocksPerCu = 6, OptRefillPrimary = 7, OptRefillBounce = 8, OptQuantized = 9, OptInstanced = 10,
+                         OptPipelineCalls = 11;
 
         [DllImport(Lib)] public static extern int pt_default_config(ref Config cfg);
         [DllImport(Lib)] public static extern int pt_create(ref Config cfg, out IntPtr ctx);

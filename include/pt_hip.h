@@ -225,7 +225,10 @@ enum { PT_OPT_NEE = 1, PT_OPT_RNG_MODE = 2, PT_OPT_TRAVERSAL_STATS = 3, PT_OPT_S
                                with boxes on a 16-bit grid (the exact leaf boxes are then applied at the triangles: hits are the
                                same), 2 (default) the 64-byte records for trees that exceed the L2 caches */,
        PT_OPT_INSTANCED = 10 /* 1: walk the instances of a scene installed by pt_build_scene_instanced (0, the default, and every
-                                scene installed another way: the flattened triangles) */ };
+                                scene installed another way: the flattened triangles) */,
+       PT_OPT_PIPELINE_CALLS = 11 /* 1 (default): consecutive pt_render calls of up to 64M paths are traced on two alternating sets of
+                                     streams and queues, so that two frames are in flight together and fill each other's tails; their
+                                     samples still enter the accumulator in call order, on the context's stream.  0: one set */ };
 int pt_set_option(pt_ctx* ctx, int32_t key, int32_t value);
 
 /* ---- multi-GPU tiles, one process per GPU --------------------------------------

@@ -119,7 +119,38 @@ struct pt_ctx {
     uint64_t local_pixels = 0;
     int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
     void* scratch_dev = nullptr;   // this device's copy of the fixed staging array (pt_trace_closest_noalloc)
+    // A second set of streams, events, control block and queues.  Consecutive render calls of moderate size alternate between the
+    // context's own set and this one: every bounce of a frame ends in a tail of a few long rays during which most of the chip idles,
+    // and two frames in flight fill each other's tails (5 % on back-to-back 1080p x 16 spp frames).  Only the traversal and shading
+    // of a call run on the second set; its planes are added to the accumulator on the context's stream, in call order, so everything
+    // queued on that stream — read-outs, resets, a caller's own work after pt_stream — is ordered after every render call before it.
+    struct Lane {
+        hipStream_t stream = nullptr, stream_connect = nullptr;
+        hipEvent_t ev_shaded = nullptr, ev_connected = nullptr, ev_done = nullptr, ev_resolved = nullptr;
+        Ctl* d_ctl = nullptr;
+        Queues q{};
+        std::vector<void*> qmem;
+        uint32_t capacity = 0;
+    } lane1;
+    bool lane1_next = false;   // which set the next eligible render call takes
+    int pipeline_calls = 1;    // PT_OPT_PIPELINE_CALLS
 };
+
+// What a render call runs on: the context's own streams, control block and queues, or the second set.
+struct LaneRef {
+    hipStream_t stream, stream_connect;
+    hipEvent_t ev_shaded, ev_connected;
+    Ctl* d_ctl;
+    Queues* q;
+    std::vector<void*>* qmem;
+    uint32_t* capacity;
+    bool second;
+};
+static LaneRef ownLane(pt_ctx* c) { return LaneRef{c->stream, c->stream_connect, c->ev_shaded, c->ev_connected, c->d_ctl, &c->q, &c->qmem, &c->capacity, false}; }
+static LaneRef secondLane(pt_ctx* c) {
+    pt_ctx::Lane& l = c->lane1;
+    return LaneRef{l.stream, l.stream_connect, l.ev_shaded, l.ev_connected, l.d_ctl, &l.q, &l.qmem, &l.capacity, true};
+}
 
 #define FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); if (ctx) (ctx)->err = _b; else g_err = _b; return (code); } while (0)
 #define HIPCHECK(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
@@ -131,6 +162,10 @@ void freeQueues(pt_ctx* c) {
     for (void* p : c->qmem) (void)hipFree(p);
     c->qmem.clear();
     c->q = Queues{};
+    for (void* p : c->lane1.qmem) (void)hipFree(p);
+    c->lane1.qmem.clear();
+    c->lane1.q = Queues{};
+    c->lane1.capacity = 0;
     if (c->d_sum) { (void)hipFree(c->d_sum); c->d_sum = nullptr; }
     if (c->d_image) { (void)hipFree(c->d_image); c->d_image = nullptr; }
     c->capacity = 0;
@@ -147,26 +182,28 @@ void freeScene(pt_ctx* c) {
 }
 
 #define PT_BYTES_PER_PATH 176u   // eleven 16-byte queue columns (allocQueues)
-int allocQueues(pt_ctx* c, uint32_t capacity) {
-    for (void* p : c->qmem) (void)hipFree(p);
-    c->qmem.clear();
+int allocQueues(pt_ctx* c, const LaneRef& L, uint32_t capacity) {
+    std::vector<void*>& qmem = *L.qmem;
+    Queues& q = *L.q;
+    for (void* p : qmem) (void)hipFree(p);
+    qmem.clear();
     // nothing may keep pointing at the freed columns if an allocation below fails
-    c->q = Queues{};
-    c->capacity = 0;
-    float4** cols[] = {&c->q.o[0], &c->q.o[1], &c->q.d[0], &c->q.d[1], &c->q.T[0], &c->q.T[1], &c->q.hit, &c->q.so, &c->q.sd, &c->q.sc, &c->q.plane};
+    q = Queues{};
+    *L.capacity = 0;
+    float4** cols[] = {&q.o[0], &q.o[1], &q.d[0], &q.d[1], &q.T[0], &q.T[1], &q.hit, &q.so, &q.sd, &q.sc, &q.plane};
     for (float4** col : cols) {
         void* p = nullptr;
         const hipError_t e = ptMalloc(&p, (size_t)capacity * sizeof(float4));
         if (e != hipSuccess) {
-            for (void* m : c->qmem) (void)hipFree(m);
-            c->qmem.clear();
-            c->q = Queues{};
+            for (void* m : qmem) (void)hipFree(m);
+            qmem.clear();
+            q = Queues{};
             FAIL(c, (e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "ray queues of %u paths: %s", capacity, hipGetErrorString(e));
         }
-        c->qmem.push_back(p);
+        qmem.push_back(p);
         *col = (float4*)p;
     }
-    c->capacity = capacity;
+    *L.capacity = capacity;
     return PT_OK;
 }
 
@@ -204,12 +241,12 @@ hipEvent_t getEvent(pt_ctx* c) {
 }
 
 struct StageTimer {
-    pt_ctx* c; int stage; hipEvent_t a = nullptr, b = nullptr;
-    StageTimer(pt_ctx* ctx, int s) : c(ctx), stage(s) {
-        if (c->cfg.stage_timing == 1 || (c->cfg.stage_timing == 2 && (s == 1 || s == 4))) { a = getEvent(c); b = getEvent(c); if (a) (void)hipEventRecord(a, c->stream); }
+    pt_ctx* c; int stage; hipStream_t on; hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(pt_ctx* ctx, int s, hipStream_t stream) : c(ctx), stage(s), on(stream) {
+        if (c->cfg.stage_timing == 1 || (c->cfg.stage_timing == 2 && (s == 1 || s == 4))) { a = getEvent(c); b = getEvent(c); if (a) (void)hipEventRecord(a, on); }
     }
     ~StageTimer() {
-        if (a && b) { (void)hipEventRecord(b, c->stream); c->spans.push_back({a, b, stage}); }
+        if (a && b) { (void)hipEventRecord(b, on); c->spans.push_back({a, b, stage}); }
     }
 };
 
@@ -474,7 +511,7 @@ static int impl_create_single(const pt_config* cfg, pt_ctx** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_shaded, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_connected, hipEventDisableTiming);
     if (e == hipSuccess) e = ptMalloc((void**)&c->d_ctl, sizeof(Ctl));
-    if (e == hipSuccess) e = hipMemset(c->d_ctl, 0, sizeof(Ctl));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_ctl, 0, sizeof(Ctl), c->stream);   // (on the stream whose kernels use it: a plain hipMemset of device memory need not be through when it returns)
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
     if (e == hipSuccess) e = resolveScratch(cfg->device, &c->scratch_dev);   // with cfg->device current
@@ -508,11 +545,13 @@ static int impl_create_single(const pt_config* cfg, pt_ctx** out) {
     return PT_OK;
 }
 
+static void freeSecondLane(pt_ctx* c);
 int pt_destroy(pt_ctx* c) {
     if (!c) return PT_OK;
     if (c->group) { destroyGroup(c); return PT_OK; }
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    freeSecondLane(c);
     freeQueues(c);
     freeScene(c);
     if (c->d_ctl) (void)hipFree(c->d_ctl);
@@ -551,6 +590,7 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
         case PT_OPT_REFILL_BOUNCE: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_bounce = value; c->refill_bounce_set = true; break;
         case PT_OPT_QUANTIZED: if (value < 0 || value > 2) FAIL(c, PT_E_INVALID_ARG, "quantized %d", value); c->quant_mode = value; break;
         case PT_OPT_INSTANCED: if (value != 0 && value != 1) FAIL(c, PT_E_INVALID_ARG, "instanced %d", value); c->inst_mode = value; break;
+        case PT_OPT_PIPELINE_CALLS: if (value != 0 && value != 1) FAIL(c, PT_E_INVALID_ARG, "pipeline_calls %d", value); c->pipeline_calls = value; break;
         case PT_OPT_SAMPLES_PER_BATCH: if (value < 0) FAIL(c, PT_E_INVALID_ARG, "samples_per_batch %d", value); c->cfg.samples_per_batch = value; break;
         default: FAIL(c, PT_E_INVALID_ARG, "unknown option %d", key);
     }
@@ -592,7 +632,7 @@ static int impl_resize(pt_ctx* c, int32_t width, int32_t height) {
     }
     HIPCHECK(c, ptMalloc((void**)&c->d_sum, (size_t)std::max(1u, c->slots_padded) * sizeof(float4)));
     HIPCHECK(c, ptMalloc((void**)&c->d_image, (size_t)width * height * sizeof(float4)));
-    HIPCHECK(c, hipMemset(c->d_sum, 0, (size_t)std::max(1u, c->slots_padded) * sizeof(float4)));
+    HIPCHECK(c, hipMemsetAsync(c->d_sum, 0, (size_t)std::max(1u, c->slots_padded) * sizeof(float4), c->stream));
     c->samples_accumulated = 0;
     c->has_rs = false;
     return PT_OK;
@@ -661,17 +701,53 @@ static bool largeWalk(const pt_ctx* c) { return c->large_tree && walkMode(c) != 
 
 // the persistent grids fill the chip: as many blocks as fit (the instanced kernels need more registers, fewer fit)
 static int traverseGrid(const pt_ctx* c, int grid) { return walkMode(c) == PT_WALK_INST ? std::min(grid, c->num_cu * c->fit_inst) : grid; }
-static void launchExtend(pt_ctx* c, bool stats, int cur, uint32_t refillMin) {
-    PT_LAUNCH_WALK(k_extend, stats, walkMode(c), dim3(traverseGrid(c, c->grid_extend)), dim3(PT_BLOCK), c->stream, c->sc, c->q, c->d_ctl, cur, refillMin);
+static void launchExtend(pt_ctx* c, const LaneRef& L, bool stats, int cur, uint32_t refillMin) {
+    PT_LAUNCH_WALK(k_extend, stats, walkMode(c), dim3(traverseGrid(c, c->grid_extend)), dim3(PT_BLOCK), L.stream, c->sc, *L.q, L.d_ctl, cur, refillMin);
 }
-static void launchConnect(pt_ctx* c, bool stats, int cur, hipStream_t on) {
-    PT_LAUNCH_WALK(k_connect, stats, walkMode(c), dim3(traverseGrid(c, c->grid_connect)), dim3(PT_BLOCK), on, c->sc, c->q, c->d_ctl, cur, bounceRefill(c));
+static void launchConnect(pt_ctx* c, const LaneRef& L, bool stats, int cur, hipStream_t on) {
+    PT_LAUNCH_WALK(k_connect, stats, walkMode(c), dim3(traverseGrid(c, c->grid_connect)), dim3(PT_BLOCK), on, c->sc, *L.q, L.d_ctl, cur, bounceRefill(c));
 }
 static void launchTrace(pt_ctx* c, bool anyhit, const TraceSource& src, int n) {
     PT_LAUNCH_WALK(k_trace, anyhit, walkMode(c), dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), c->stream, c->sc, src, n, c->d_ctl);
 }
 
-static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32_t max_bounces, bool generate_only) {
+// The second set of streams, events and control block, made when the first render call takes it.
+static int ensureSecondLane(pt_ctx* c) {
+    pt_ctx::Lane& l = c->lane1;
+    if (l.stream) return PT_OK;
+    hipError_t e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream_connect, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev_shaded, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev_connected, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev_resolved, hipEventDisableTiming);
+    if (e == hipSuccess) e = ptMalloc((void**)&l.d_ctl, sizeof(Ctl));
+    if (e == hipSuccess) e = hipMemsetAsync(l.d_ctl, 0, sizeof(Ctl), l.stream);   // on the stream whose kernels use it: ordered before them
+    if (e != hipSuccess) {
+        if (l.d_ctl) { (void)hipFree(l.d_ctl); l.d_ctl = nullptr; }
+        for (hipEvent_t* ev : {&l.ev_shaded, &l.ev_connected, &l.ev_done, &l.ev_resolved}) { if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; } }
+        if (l.stream_connect) { (void)hipStreamDestroy(l.stream_connect); l.stream_connect = nullptr; }
+        if (l.stream) { (void)hipStreamDestroy(l.stream); l.stream = nullptr; }
+        FAIL(c, (e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "second set of streams: %s", hipGetErrorString(e));
+    }
+    return PT_OK;
+}
+
+static void freeSecondLane(pt_ctx* c) {
+    pt_ctx::Lane& l = c->lane1;
+    if (l.stream) (void)hipStreamSynchronize(l.stream);
+    if (l.stream_connect) (void)hipStreamSynchronize(l.stream_connect);
+    for (void* p : l.qmem) (void)hipFree(p);
+    l.qmem.clear();
+    l.q = Queues{};
+    l.capacity = 0;
+    if (l.d_ctl) { (void)hipFree(l.d_ctl); l.d_ctl = nullptr; }
+    for (hipEvent_t* ev : {&l.ev_shaded, &l.ev_connected, &l.ev_done, &l.ev_resolved}) { if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; } }
+    if (l.stream_connect) { (void)hipStreamDestroy(l.stream_connect); l.stream_connect = nullptr; }
+    if (l.stream) { (void)hipStreamDestroy(l.stream); l.stream = nullptr; }
+}
+
+static int renderBatches(pt_ctx* c, const LaneRef& L, const HostFrameState& fs, int32_t spp, int32_t max_bounces, bool generate_only) {
     RenderParams rp{};
     rp.width = c->width;
     rp.height = c->height;
@@ -687,12 +763,16 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
 
     const uint32_t batch = generate_only ? 1u : chooseBatch(c, (uint32_t)spp);
     const uint32_t need = c->slots * batch;
-    if (need > c->capacity) {
-        HIPCHECK(c, hipStreamSynchronize(c->stream));
-        int rc = allocQueues(c, need);
+    if (need > *L.capacity) {
+        // the set's queues are replaced: whatever still reads them (its own streams; the accumulation of its planes, which runs on
+        // the context's stream) has to be through
+        HIPCHECK(c, hipStreamSynchronize(L.stream));
+        if (L.second) HIPCHECK(c, hipStreamSynchronize(c->stream));
+        int rc = allocQueues(c, L, need);
         if (rc != PT_OK) return rc;
     }
     if (c->slots == 0) return PT_OK;
+    const Queues& q = *L.q;
 
     for (uint32_t s0 = 0; s0 < (uint32_t)spp; s0 += batch) {
         const uint32_t ns = std::min(batch, (uint32_t)spp - s0);
@@ -703,12 +783,15 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
         // dense batches: every slot is a path, and shade of bounce 0 stores each path's first value itself
         rp.plane_fresh = (dense && !generate_only) ? 1 : 0;
         rp.group_major = (!generate_only && largeWalk(c)) ? 1 : 0;
-        if (!rp.plane_fresh) HIPCHECK(c, hipMemsetAsync(c->q.plane, 0, (size_t)total * sizeof(float4), c->stream));
-        hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, dense ? total : 0u, 0ull);
+        // the second set's planes are read by an accumulation that runs on the context's stream: the batch before this one on this
+        // set (of this call or of an earlier one) must have been added before its planes are written again
+        if (L.second) HIPCHECK(c, hipStreamWaitEvent(L.stream, c->lane1.ev_resolved, 0));
+        if (!rp.plane_fresh) HIPCHECK(c, hipMemsetAsync(q.plane, 0, (size_t)total * sizeof(float4), L.stream));
+        hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, L.stream, L.d_ctl, dense ? total : 0u, 0ull);
         {
-            StageTimer t(c, 0);
-            if (dense) hipLaunchKernelGGL(k_generate<true>, dim3(launchGrid(total)), dim3(PT_BLOCK), 0, c->stream, rp, c->q, c->d_ctl);
-            else hipLaunchKernelGGL(k_generate<false>, dim3(launchGrid(total)), dim3(PT_BLOCK), 0, c->stream, rp, c->q, c->d_ctl);
+            StageTimer t(c, 0, L.stream);
+            if (dense) hipLaunchKernelGGL(k_generate<true>, dim3(launchGrid(total)), dim3(PT_BLOCK), 0, L.stream, rp, q, L.d_ctl);
+            else hipLaunchKernelGGL(k_generate<false>, dim3(launchGrid(total)), dim3(PT_BLOCK), 0, L.stream, rp, q, L.d_ctl);
             c->host_stats.generate_launches++;
         }
         if (generate_only) break;
@@ -720,40 +803,46 @@ static int renderBatches(pt_ctx* c, const HostFrameState& fs, int32_t spp, int32
         // a way out of this loop with a connect still running on its stream (a failed call below) waits for it: everything else
         // in the library orders itself after the context's main stream only
         struct Join {
-            pt_ctx* c; bool* pending;
-            ~Join() { if (*pending) (void)hipStreamSynchronize(c->stream_connect); }
-        } join{c, &connectPending};
+            hipStream_t on; bool* pending;
+            ~Join() { if (*pending) (void)hipStreamSynchronize(on); }
+        } join{L.stream_connect, &connectPending};
         for (int b = 0; b < max_bounces; b++) {
             rp.bounce = b;
             rp.last_bounce = (b == max_bounces - 1) ? 1 : 0;
             {
-                StageTimer t(c, b == 0 ? 4 : 1);
-                launchExtend(c, stats, cur, (uint32_t)(b == 0 ? ((largeWalk(c) && !c->refill_primary_set) ? 32 : c->refill_primary) : bounceRefill(c)));
+                StageTimer t(c, b == 0 ? 4 : 1, L.stream);
+                launchExtend(c, L, stats, cur, (uint32_t)(b == 0 ? ((largeWalk(c) && !c->refill_primary_set) ? 32 : c->refill_primary) : bounceRefill(c)));
                 c->host_stats.extend_launches++;
             }
-            if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_connected, 0)); connectPending = false; }
+            if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(L.stream, L.ev_connected, 0)); connectPending = false; }
             {
-                StageTimer t(c, 2);
-                hipLaunchKernelGGL(k_shade, dim3(c->grid_shade), dim3(PT_SHADE_BLOCK), 0, c->stream, c->sc, rp, c->q, c->d_ctl, cur);
+                StageTimer t(c, 2, L.stream);
+                hipLaunchKernelGGL(k_shade, dim3(c->grid_shade), dim3(PT_SHADE_BLOCK), 0, L.stream, c->sc, rp, q, L.d_ctl, cur);
                 c->host_stats.shade_launches++;
             }
             if (rp.nee && c->sc.n_lights > 0) {
-                StageTimer t(c, 3);
-                hipStream_t on = c->stream;
+                StageTimer t(c, 3, L.stream);
+                hipStream_t on = L.stream;
                 if (beside) {
-                    HIPCHECK(c, hipEventRecord(c->ev_shaded, c->stream));
-                    HIPCHECK(c, hipStreamWaitEvent(c->stream_connect, c->ev_shaded, 0));
-                    on = c->stream_connect;
+                    HIPCHECK(c, hipEventRecord(L.ev_shaded, L.stream));
+                    HIPCHECK(c, hipStreamWaitEvent(L.stream_connect, L.ev_shaded, 0));
+                    on = L.stream_connect;
                 }
-                launchConnect(c, stats, cur, on);
-                if (beside) { HIPCHECK(c, hipEventRecord(c->ev_connected, c->stream_connect)); connectPending = true; }
+                launchConnect(c, L, stats, cur, on);
+                if (beside) { HIPCHECK(c, hipEventRecord(L.ev_connected, L.stream_connect)); connectPending = true; }
                 c->host_stats.connect_launches++;
             }
             cur ^= 1;
         }
-        if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_connected, 0)); connectPending = false; }
-        hipLaunchKernelGGL(k_resolve, dim3(launchGrid(c->slots)), dim3(PT_BLOCK), 0, c->stream, c->d_sum, (const float4*)c->q.plane, c->slots, ns);
-        hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, 0u, (unsigned long long)c->local_pixels * ns);
+        if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(L.stream, L.ev_connected, 0)); connectPending = false; }
+        hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, L.stream, L.d_ctl, 0u, (unsigned long long)c->local_pixels * ns);
+        // the batch's planes go into the accumulator on the context's stream: calls add up in the order they were made
+        if (L.second) {
+            HIPCHECK(c, hipEventRecord(c->lane1.ev_done, L.stream));
+            HIPCHECK(c, hipStreamWaitEvent(c->stream, c->lane1.ev_done, 0));
+        }
+        hipLaunchKernelGGL(k_resolve, dim3(launchGrid(c->slots)), dim3(PT_BLOCK), 0, c->stream, c->d_sum, (const float4*)q.plane, c->slots, ns);
+        if (L.second) HIPCHECK(c, hipEventRecord(c->lane1.ev_resolved, c->stream));
     }
     HIPCHECK(c, hipGetLastError());
     return PT_OK;
@@ -777,8 +866,22 @@ static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32
         c->samples_accumulated = 0;
     }
     HIPCHECK(c, hipEventRecord(c->ev_begin, c->stream));
-    int rc = renderBatches(c, fs, spp, max_bounces, false);
-    if (rc != PT_OK) return rc;
+    // Calls of up to 64M paths alternate between the two sets of streams and queues (11 GB each at most), so that two consecutive
+    // frames are in flight together; larger calls are long enough for their tails not to matter and take the context's own set.
+    // With per-stage timing the stages of a call have the GPU to themselves.
+    const bool eligible = c->pipeline_calls != 0 && c->cfg.stage_timing != 1 && (uint64_t)c->slots * chooseBatch(c, (uint32_t)spp) <= (64ull << 20);
+    LaneRef L = ownLane(c);
+    if (eligible && c->lane1_next) {
+        const int rs = ensureSecondLane(c);
+        if (rs != PT_OK) return rs;
+        L = secondLane(c);
+    }
+    c->lane1_next = eligible ? !c->lane1_next : true;
+    int rc = renderBatches(c, L, fs, spp, max_bounces, false);
+    if (rc != PT_OK) {
+        if (L.second) { (void)hipStreamSynchronize(L.stream); (void)hipStreamSynchronize(L.stream_connect); }   // nothing of a failed call stays behind on the second set
+        return rc;
+    }
     HIPCHECK(c, hipEventRecord(c->ev_end, c->stream));
     c->render_pending = true;
     c->samples_accumulated += (uint32_t)spp;
@@ -795,7 +898,7 @@ int pt_synchronize(pt_ctx* c) {
         return PT_OK;
     }
     HIPCHECK(c, hipSetDevice(c->cfg.device));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));   // (which has waited for every batch traced on the second set)
     if (c->render_pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->host_stats.ms_render = ms;
@@ -975,7 +1078,7 @@ static int impl_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, 
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HostFrameState fs;
     memcpy(&fs, frame_state112, sizeof(fs));
-    int rc = renderBatches(c, fs, 1, 1, true);
+    int rc = renderBatches(c, ownLane(c), fs, 1, 1, true);
     if (rc != PT_OK) return rc;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     Ctl ctl;
@@ -998,7 +1101,7 @@ static int impl_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, 
         o_d[6 * birth + 3] = d[j].x; o_d[6 * birth + 4] = d[j].y; o_d[6 * birth + 5] = d[j].z;
     }
     // the debug batch must not count as rendered samples
-    HIPCHECK(c, hipMemset(c->d_ctl, 0, offsetof(Ctl, paths)));
+    HIPCHECK(c, hipMemsetAsync(c->d_ctl, 0, offsetof(Ctl, paths), c->stream));
     return PT_OK;
 }
 
@@ -1013,7 +1116,7 @@ static int impl_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t ite
     if (!c->has_scene) FAIL(c, PT_E_STATE, "pt_bench_extend before pt_upload_scene");
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
-    if ((uint32_t)n > c->capacity) { int rc = allocQueues(c, (uint32_t)n); if (rc != PT_OK) return rc; }
+    if ((uint32_t)n > c->capacity) { int rc = allocQueues(c, ownLane(c), (uint32_t)n); if (rc != PT_OK) return rc; }
     std::vector<float4> o((size_t)n), d((size_t)n);
     for (int i = 0; i < n; i++) {
         o[i] = make_float4(o_d[6 * i], o_d[6 * i + 1], o_d[6 * i + 2], 0.0f);
@@ -1028,7 +1131,7 @@ static int impl_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t ite
     for (int it = 0; it < iters + 1; it++) {   // the first launch warms caches and is not counted
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, (uint32_t)n, 0ull);
         HIPCHECK(c, hipEventRecord(a, c->stream));
-        launchExtend(c, stats, 0, bounceRefill(c));
+        launchExtend(c, ownLane(c), stats, 0, bounceRefill(c));
         HIPCHECK(c, hipEventRecord(b, c->stream));
         HIPCHECK(c, hipStreamSynchronize(c->stream));
         float ms = 0.0f;
@@ -1600,6 +1703,14 @@ static int gatherStats(pt_ctx* c, pt_stats* out) {
     if (rc != PT_OK) return rc;
     Ctl ctl;
     HIPCHECK(c, hipMemcpy(&ctl, c->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    if (c->lane1.d_ctl) {   // calls traced on the second set counted there
+        Ctl two;
+        HIPCHECK(c, hipMemcpy(&two, c->lane1.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+        ctl.paths += two.paths; ctl.extend_rays += two.extend_rays; ctl.shadow_rays += two.shadow_rays; ctl.extend_steps += two.extend_steps;
+        ctl.extend_tris += two.extend_tris; ctl.shadow_steps += two.shadow_steps; ctl.shadow_tris += two.shadow_tris; ctl.stack_overflows += two.stack_overflows;
+        ctl.sched_interior += two.sched_interior; ctl.sched_leaf += two.sched_leaf; ctl.sched_refill += two.sched_refill; ctl.special_rays += two.special_rays;
+        ctl.unique_steps += two.unique_steps; ctl.unique_tris += two.unique_tris; ctl.shadow_occluded += two.shadow_occluded;
+    }
     pt_stats s = c->host_stats;
     s.paths = ctl.paths;
     s.extend_rays = ctl.extend_rays;
@@ -1632,7 +1743,8 @@ int pt_reset_stats(pt_ctx* c) {
     }
     int rc = pt_synchronize(c);
     if (rc != PT_OK) return rc;
-    HIPCHECK(c, hipMemset(c->d_ctl, 0, sizeof(Ctl)));
+    HIPCHECK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Ctl), c->stream));
+    if (c->lane1.d_ctl) HIPCHECK(c, hipMemsetAsync(c->lane1.d_ctl, 0, sizeof(Ctl), c->lane1.stream));   // each on the stream that uses it next
     c->host_stats = pt_stats{};
     return PT_OK;
 }

@@ -55,6 +55,10 @@ def main():
     both = run(ctxs, args.frames, half)
     print(f"{args.contexts} contexts, {args.frames} frames of {half} spp each, concurrently: {both / args.frames:.3f} ms per {args.spp}-spp frame equivalent "
           f"({one / both:.3f}x)", flush=True)
+    # the contexts render whole frames side by side: what pipelining consecutive frames of one context would give
+    full = run(ctxs, args.frames, args.spp)
+    print(f"{args.contexts} contexts, {args.frames} frames of {args.spp} spp each, concurrently: {full / args.frames / args.contexts:.3f} ms per frame "
+          f"({one * args.contexts / full:.3f}x)", flush=True)
     for wf in ctxs:
         wf.close()
 
