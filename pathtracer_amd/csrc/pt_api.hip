@@ -71,6 +71,10 @@ struct pt_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream_connect = nullptr;   // the connect stage of a bounce runs here, beside extend of the next bounce
     hipEvent_t ev_shaded = nullptr, ev_connected = nullptr;
+    // `stream` is the context's ordering point: accumulation, read-outs, queries, whatever a caller queues after pt_stream.  A render
+    // call traces on a stream of its own (this one for the context's first set of queues) and hands its planes over through two events.
+    hipStream_t stream_render = nullptr;
+    hipEvent_t ev_done0 = nullptr, ev_resolved0 = nullptr;
     int num_cu = 256;
     // scene
     DevScene sc{};
@@ -120,13 +124,14 @@ struct pt_ctx {
     int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
     void* scratch_dev = nullptr;   // this device's copy of the fixed staging array (pt_trace_closest_noalloc)
     // A second set of streams, events, control block and queues.  Consecutive render calls of moderate size alternate between the
-    // context's own set and this one: every bounce of a frame ends in a tail of a few long rays during which most of the chip idles,
-    // and two frames in flight fill each other's tails (5 % on back-to-back 1080p x 16 spp frames).  Only the traversal and shading
-    // of a call run on the second set; its planes are added to the accumulator on the context's stream, in call order, so everything
-    // queued on that stream — read-outs, resets, a caller's own work after pt_stream — is ordered after every render call before it.
+    // context's first set and this one: every bounce of a frame ends in a tail of a few long rays during which most of the chip idles,
+    // and two frames in flight fill each other's tails (5 % on back-to-back 1080p x 16 spp frames, more on small ones).  Only the
+    // traversal and shading of a call run on a set's streams; its planes are added to the accumulator on the context's stream, in call
+    // order, so everything queued on that stream — read-outs, resets, a caller's own work after pt_stream — is ordered after every
+    // render call made before it.
     struct Lane {
-        hipStream_t stream = nullptr, stream_connect = nullptr;
-        hipEvent_t ev_shaded = nullptr, ev_connected = nullptr, ev_done = nullptr, ev_resolved = nullptr;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_done = nullptr, ev_resolved = nullptr;
         Ctl* d_ctl = nullptr;
         Queues q{};
         std::vector<void*> qmem;
@@ -136,20 +141,29 @@ struct pt_ctx {
     int pipeline_calls = 1;    // PT_OPT_PIPELINE_CALLS
 };
 
-// What a render call runs on: the context's own streams, control block and queues, or the second set.
+// What a render call runs on.  `hop`: the traversal stream is not the context's stream, so the batch's end is handed over by ev_done;
+// ev_resolved (recorded on the context's stream after the planes were added) is what the set's next batch waits for.
 struct LaneRef {
     hipStream_t stream, stream_connect;
-    hipEvent_t ev_shaded, ev_connected;
+    hipEvent_t ev_shaded, ev_connected, ev_done, ev_resolved;
     Ctl* d_ctl;
     Queues* q;
     std::vector<void*>* qmem;
     uint32_t* capacity;
-    bool second;
+    bool hop;
 };
-static LaneRef ownLane(pt_ctx* c) { return LaneRef{c->stream, c->stream_connect, c->ev_shaded, c->ev_connected, c->d_ctl, &c->q, &c->qmem, &c->capacity, false}; }
+// the first set on its own traversal stream (calls that may overlap with their neighbours)
+static LaneRef ownLane(pt_ctx* c) {
+    return LaneRef{c->stream_render, nullptr, nullptr, nullptr, c->ev_done0, c->ev_resolved0, c->d_ctl, &c->q, &c->qmem, &c->capacity, true};
+}
+// the first set on the context's stream itself: after everything queued before, before everything queued after (per-stage timing,
+// very large calls, the debugging entry points)
+static LaneRef inlineLane(pt_ctx* c) {
+    return LaneRef{c->stream, c->stream_connect, c->ev_shaded, c->ev_connected, nullptr, c->ev_resolved0, c->d_ctl, &c->q, &c->qmem, &c->capacity, false};
+}
 static LaneRef secondLane(pt_ctx* c) {
     pt_ctx::Lane& l = c->lane1;
-    return LaneRef{l.stream, l.stream_connect, l.ev_shaded, l.ev_connected, l.d_ctl, &l.q, &l.qmem, &l.capacity, true};
+    return LaneRef{l.stream, nullptr, nullptr, nullptr, l.ev_done, l.ev_resolved, l.d_ctl, &l.q, &l.qmem, &l.capacity, true};
 }
 
 #define FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); if (ctx) (ctx)->err = _b; else g_err = _b; return (code); } while (0)
@@ -508,10 +522,14 @@ static int impl_create_single(const pt_config* cfg, pt_ctx** out) {
     hipError_t e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_connect, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_render, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done0, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_resolved0, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_shaded, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_connected, hipEventDisableTiming);
     if (e == hipSuccess) e = ptMalloc((void**)&c->d_ctl, sizeof(Ctl));
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_ctl, 0, sizeof(Ctl), c->stream);   // (on the stream whose kernels use it: a plain hipMemset of device memory need not be through when it returns)
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_ctl, 0, sizeof(Ctl), c->stream);   // (a plain hipMemset of device memory need not be through when it returns)
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
     if (e == hipSuccess) e = resolveScratch(cfg->device, &c->scratch_dev);   // with cfg->device current
@@ -551,6 +569,9 @@ int pt_destroy(pt_ctx* c) {
     if (c->group) { destroyGroup(c); return PT_OK; }
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream_render) { (void)hipStreamSynchronize(c->stream_render); (void)hipStreamDestroy(c->stream_render); }
+    if (c->ev_done0) (void)hipEventDestroy(c->ev_done0);
+    if (c->ev_resolved0) (void)hipEventDestroy(c->ev_resolved0);
     freeSecondLane(c);
     freeQueues(c);
     freeScene(c);
@@ -716,17 +737,13 @@ static int ensureSecondLane(pt_ctx* c) {
     pt_ctx::Lane& l = c->lane1;
     if (l.stream) return PT_OK;
     hipError_t e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream_connect, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev_shaded, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev_connected, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&l.ev_resolved, hipEventDisableTiming);
     if (e == hipSuccess) e = ptMalloc((void**)&l.d_ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipMemsetAsync(l.d_ctl, 0, sizeof(Ctl), l.stream);   // on the stream whose kernels use it: ordered before them
     if (e != hipSuccess) {
         if (l.d_ctl) { (void)hipFree(l.d_ctl); l.d_ctl = nullptr; }
-        for (hipEvent_t* ev : {&l.ev_shaded, &l.ev_connected, &l.ev_done, &l.ev_resolved}) { if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; } }
-        if (l.stream_connect) { (void)hipStreamDestroy(l.stream_connect); l.stream_connect = nullptr; }
+        for (hipEvent_t* ev : {&l.ev_done, &l.ev_resolved}) { if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; } }
         if (l.stream) { (void)hipStreamDestroy(l.stream); l.stream = nullptr; }
         FAIL(c, (e == hipErrorOutOfMemory ? PT_E_OOM : PT_E_HIP), "second set of streams: %s", hipGetErrorString(e));
     }
@@ -736,14 +753,12 @@ static int ensureSecondLane(pt_ctx* c) {
 static void freeSecondLane(pt_ctx* c) {
     pt_ctx::Lane& l = c->lane1;
     if (l.stream) (void)hipStreamSynchronize(l.stream);
-    if (l.stream_connect) (void)hipStreamSynchronize(l.stream_connect);
     for (void* p : l.qmem) (void)hipFree(p);
     l.qmem.clear();
     l.q = Queues{};
     l.capacity = 0;
     if (l.d_ctl) { (void)hipFree(l.d_ctl); l.d_ctl = nullptr; }
-    for (hipEvent_t* ev : {&l.ev_shaded, &l.ev_connected, &l.ev_done, &l.ev_resolved}) { if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; } }
-    if (l.stream_connect) { (void)hipStreamDestroy(l.stream_connect); l.stream_connect = nullptr; }
+    for (hipEvent_t* ev : {&l.ev_done, &l.ev_resolved}) { if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; } }
     if (l.stream) { (void)hipStreamDestroy(l.stream); l.stream = nullptr; }
 }
 
@@ -767,7 +782,8 @@ static int renderBatches(pt_ctx* c, const LaneRef& L, const HostFrameState& fs, 
         // the set's queues are replaced: whatever still reads them (its own streams; the accumulation of its planes, which runs on
         // the context's stream) has to be through
         HIPCHECK(c, hipStreamSynchronize(L.stream));
-        if (L.second) HIPCHECK(c, hipStreamSynchronize(c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream_render));   // (the first set is used from two streams)
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
         int rc = allocQueues(c, L, need);
         if (rc != PT_OK) return rc;
     }
@@ -783,9 +799,9 @@ static int renderBatches(pt_ctx* c, const LaneRef& L, const HostFrameState& fs, 
         // dense batches: every slot is a path, and shade of bounce 0 stores each path's first value itself
         rp.plane_fresh = (dense && !generate_only) ? 1 : 0;
         rp.group_major = (!generate_only && largeWalk(c)) ? 1 : 0;
-        // the second set's planes are read by an accumulation that runs on the context's stream: the batch before this one on this
-        // set (of this call or of an earlier one) must have been added before its planes are written again
-        if (L.second) HIPCHECK(c, hipStreamWaitEvent(L.stream, c->lane1.ev_resolved, 0));
+        // a set's planes are read by an accumulation that runs on the context's stream: the batch before this one on this set (of
+        // this call or of an earlier one) must have been added before its planes, queues and counters are written again
+        HIPCHECK(c, hipStreamWaitEvent(L.stream, L.ev_resolved, 0));
         if (!rp.plane_fresh) HIPCHECK(c, hipMemsetAsync(q.plane, 0, (size_t)total * sizeof(float4), L.stream));
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, L.stream, L.d_ctl, dense ? total : 0u, 0ull);
         {
@@ -797,14 +813,17 @@ static int renderBatches(pt_ctx* c, const LaneRef& L, const HostFrameState& fs, 
         if (generate_only) break;
         int cur = 0;
         // connect(b) only meets shade(b) (its rays) and shade(b + 1) (the planes, the shadow queue, the cursors): it runs on a
-        // stream of its own beside extend(b + 1), whose tail it fills.  Per-stage timing keeps the stages apart on one stream.
-        const bool beside = c->cfg.stage_timing != 1;
+        // stream of its own beside extend(b + 1), whose tail it fills.  Per-stage timing keeps the stages apart on one stream, and
+        // so does a call that overlaps with its neighbour (it was given no connect stream): the other frame fills the tails then,
+        // and a fifth stream would share a hardware queue (four per process) with the context's stream, whose waits would hold its
+        // kernels back (measured: 1 % from two frames in flight with a connect stream per set, 4.4 % without).
+        const bool beside = c->cfg.stage_timing != 1 && L.stream_connect != nullptr;
         bool connectPending = false;
         // a way out of this loop with a connect still running on its stream (a failed call below) waits for it: everything else
         // in the library orders itself after the context's main stream only
         struct Join {
             hipStream_t on; bool* pending;
-            ~Join() { if (*pending) (void)hipStreamSynchronize(on); }
+            ~Join() { if (*pending && on) (void)hipStreamSynchronize(on); }
         } join{L.stream_connect, &connectPending};
         for (int b = 0; b < max_bounces; b++) {
             rp.bounce = b;
@@ -837,12 +856,12 @@ static int renderBatches(pt_ctx* c, const LaneRef& L, const HostFrameState& fs, 
         if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(L.stream, L.ev_connected, 0)); connectPending = false; }
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, L.stream, L.d_ctl, 0u, (unsigned long long)c->local_pixels * ns);
         // the batch's planes go into the accumulator on the context's stream: calls add up in the order they were made
-        if (L.second) {
-            HIPCHECK(c, hipEventRecord(c->lane1.ev_done, L.stream));
-            HIPCHECK(c, hipStreamWaitEvent(c->stream, c->lane1.ev_done, 0));
+        if (L.hop) {
+            HIPCHECK(c, hipEventRecord(L.ev_done, L.stream));
+            HIPCHECK(c, hipStreamWaitEvent(c->stream, L.ev_done, 0));
         }
         hipLaunchKernelGGL(k_resolve, dim3(launchGrid(c->slots)), dim3(PT_BLOCK), 0, c->stream, c->d_sum, (const float4*)q.plane, c->slots, ns);
-        if (L.second) HIPCHECK(c, hipEventRecord(c->lane1.ev_resolved, c->stream));
+        HIPCHECK(c, hipEventRecord(L.ev_resolved, c->stream));
     }
     HIPCHECK(c, hipGetLastError());
     return PT_OK;
@@ -870,16 +889,28 @@ static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32
     // frames are in flight together; larger calls are long enough for their tails not to matter and take the context's own set.
     // With per-stage timing the stages of a call have the GPU to themselves.
     const bool eligible = c->pipeline_calls != 0 && c->cfg.stage_timing != 1 && (uint64_t)c->slots * chooseBatch(c, (uint32_t)spp) <= (64ull << 20);
-    LaneRef L = ownLane(c);
-    if (eligible && c->lane1_next) {
-        const int rs = ensureSecondLane(c);
-        if (rs != PT_OK) return rs;
-        L = secondLane(c);
+    LaneRef L = inlineLane(c);
+    if (eligible) {
+        if (c->lane1_next) {
+            const int rs = ensureSecondLane(c);
+            if (rs != PT_OK) return rs;
+            L = secondLane(c);
+        } else {
+            L = ownLane(c);
+        }
+        // a call that finds the other set idle (a host that waits for every frame) has nobody to fill its tails: it gets the
+        // connect stream, as a call on the context's stream does
+        hipEvent_t const other = c->lane1_next ? c->ev_done0 : c->lane1.ev_done;
+        if (other == nullptr || hipEventQuery(other) != hipErrorNotReady) {
+            L.stream_connect = c->stream_connect;
+            L.ev_shaded = c->ev_shaded;
+            L.ev_connected = c->ev_connected;
+        }
+        c->lane1_next = !c->lane1_next;
     }
-    c->lane1_next = eligible ? !c->lane1_next : true;
     int rc = renderBatches(c, L, fs, spp, max_bounces, false);
     if (rc != PT_OK) {
-        if (L.second) { (void)hipStreamSynchronize(L.stream); (void)hipStreamSynchronize(L.stream_connect); }   // nothing of a failed call stays behind on the second set
+        if (L.hop) (void)hipStreamSynchronize(L.stream);   // nothing of a failed call stays behind on a set's stream
         return rc;
     }
     HIPCHECK(c, hipEventRecord(c->ev_end, c->stream));
@@ -1078,7 +1109,7 @@ static int impl_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, 
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HostFrameState fs;
     memcpy(&fs, frame_state112, sizeof(fs));
-    int rc = renderBatches(c, ownLane(c), fs, 1, 1, true);
+    int rc = renderBatches(c, inlineLane(c), fs, 1, 1, true);
     if (rc != PT_OK) return rc;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     Ctl ctl;
@@ -1102,6 +1133,7 @@ static int impl_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, 
     }
     // the debug batch must not count as rendered samples
     HIPCHECK(c, hipMemsetAsync(c->d_ctl, 0, offsetof(Ctl, paths), c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
     return PT_OK;
 }
 
@@ -1116,7 +1148,7 @@ static int impl_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t ite
     if (!c->has_scene) FAIL(c, PT_E_STATE, "pt_bench_extend before pt_upload_scene");
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
-    if ((uint32_t)n > c->capacity) { int rc = allocQueues(c, ownLane(c), (uint32_t)n); if (rc != PT_OK) return rc; }
+    if ((uint32_t)n > c->capacity) { int rc = allocQueues(c, inlineLane(c), (uint32_t)n); if (rc != PT_OK) return rc; }
     std::vector<float4> o((size_t)n), d((size_t)n);
     for (int i = 0; i < n; i++) {
         o[i] = make_float4(o_d[6 * i], o_d[6 * i + 1], o_d[6 * i + 2], 0.0f);
@@ -1131,7 +1163,7 @@ static int impl_bench_extend(pt_ctx* c, const float* o_d, int32_t n, int32_t ite
     for (int it = 0; it < iters + 1; it++) {   // the first launch warms caches and is not counted
         hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, c->stream, c->d_ctl, (uint32_t)n, 0ull);
         HIPCHECK(c, hipEventRecord(a, c->stream));
-        launchExtend(c, ownLane(c), stats, 0, bounceRefill(c));
+        launchExtend(c, inlineLane(c), stats, 0, bounceRefill(c));
         HIPCHECK(c, hipEventRecord(b, c->stream));
         HIPCHECK(c, hipStreamSynchronize(c->stream));
         float ms = 0.0f;
@@ -1744,7 +1776,8 @@ int pt_reset_stats(pt_ctx* c) {
     int rc = pt_synchronize(c);
     if (rc != PT_OK) return rc;
     HIPCHECK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Ctl), c->stream));
-    if (c->lane1.d_ctl) HIPCHECK(c, hipMemsetAsync(c->lane1.d_ctl, 0, sizeof(Ctl), c->lane1.stream));   // each on the stream that uses it next
+    if (c->lane1.d_ctl) HIPCHECK(c, hipMemsetAsync(c->lane1.d_ctl, 0, sizeof(Ctl), c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));   // (the control blocks are used from other streams next)
     c->host_stats = pt_stats{};
     return PT_OK;
 }
