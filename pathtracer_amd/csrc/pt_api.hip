@@ -891,13 +891,19 @@ static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32
     const bool eligible = c->pipeline_calls != 0 && c->cfg.stage_timing != 1 && (uint64_t)c->slots * chooseBatch(c, (uint32_t)spp) <= (64ull << 20);
     LaneRef L = inlineLane(c);
     if (eligible) {
-        if (c->lane1_next) {
-            const int rs = ensureSecondLane(c);
-            if (rs != PT_OK) return rs;
-            L = secondLane(c);
-        } else {
-            L = ownLane(c);
+        // both sets are made ready by the first call that could use them: the second set's queues are not allocated in the middle
+        // of a run of frames
+        const int rs = ensureSecondLane(c);
+        if (rs != PT_OK) return rs;
+        const uint32_t need = c->slots * chooseBatch(c, (uint32_t)spp);
+        for (const LaneRef& each : {ownLane(c), secondLane(c)}) {
+            if (need <= *each.capacity) continue;
+            HIPCHECK(c, hipStreamSynchronize(each.stream));
+            HIPCHECK(c, hipStreamSynchronize(c->stream));
+            const int ra = allocQueues(c, each, need);
+            if (ra != PT_OK) return ra;
         }
+        L = c->lane1_next ? secondLane(c) : ownLane(c);
         // a call that finds the other set idle (a host that waits for every frame) has nobody to fill its tails: it gets the
         // connect stream, as a call on the context's stream does
         hipEvent_t const other = c->lane1_next ? c->ev_done0 : c->lane1.ev_done;
