@@ -480,9 +480,18 @@ def main():
     stage_ms = {k: staged["ms_" + k] for k in ("generate", "extend", "shade", "connect")}
     wf.set_option(4, 2)   # the timed steps bracket only the extend launches (every pair of events costs stream time)
     dt, st = timed_steps(run, args.steps, args.warmup, sync_all)
+    # The timed steps run two frames in flight (consecutive pt_render calls overlap): an extend launch then shares the GPU with the
+    # other frame's kernels, and the span between the events around it includes the time its blocks wait to be placed.  The kernel's
+    # own launch duration — what the roofline divides by, and what rocprofv3's kernel statistics of this command show — is taken from
+    # a few more frames with one frame in flight (connect of a bounce still beside extend of the next, as a lone frame runs).
+    st_span = st
+    if not getattr(args, "no_pipeline", False):
+        wf.set_option(11, 0)
+        _, st = timed_steps(run, min(args.steps, 3), 0, sync_all)
+        wf.set_option(11, 1)
 
     red_dev = "cuda" if (args.backend == "nccl" or world == 1) else "cpu"
-    tot = torch.tensor([float(st["extend_rays"]), float(st["shadow_rays"])], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(st_span["extend_rays"]), float(st_span["shadow_rays"])], dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -507,6 +516,10 @@ def main():
         bounce_ms = st["ms_extend"] - st["ms_extend_primary"]
         roof["bounce_extend_mrays_per_s"] = bounce_rays / max(1e-9, bounce_ms * 1e-3) / 1e6
         roof["primary_extend_mrays_per_s"] = st["paths"] / max(1e-9, st["ms_extend_primary"] * 1e-3) / 1e6
+        if st_span is not st:
+            roof["launch_timing"] = ("HIP events around the extend launches of frames rendered one at a time after the timed steps; in the timed steps two frames are "
+                                     "in flight and the same events span %.3f ms per launch, queueing behind the other frame included"
+                                     % (st_span["ms_extend"] / max(1, st_span["extend_launches"])))
         overridden = args.spp or args.width or args.height or args.bounces
         out = {
             "metric": "Mrays/s (primary+bounce+shadow rays traced)", "value": (extend_rays + shadow_rays) / dt / 1e6, "unit": "Mrays/s",
