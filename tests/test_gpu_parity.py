@@ -879,6 +879,57 @@ def test_batch_size_and_accumulation_invariance(pa, bundled, w, h):
         assert np.array_equal(bits(im), bits(imgs[0]))
 
 
+def test_overlapping_render_calls(pa, ob, bundled):
+    """Consecutive pt_render calls are traced on two alternating sets of queues and overlap on the device; their samples enter the
+    accumulator in call order on the context's stream.  A run of calls queued without waiting — single- and multi-batch, a reset of
+    the accumulation in the middle, a read-out and a closest-hit query between calls, a resize — must give the bits and the
+    counters of the same run with the second set switched off (PT_OPT_PIPELINE_CALLS = 0), and the first frame those of the oracle."""
+    w, h = 160, 96
+    got = {}
+    for pipe in (1, 0):
+        for batch in (0, 1):
+            wf = make_wf(pa, bundled, nee=True, rng_mode=1, traversal_stats=True, samples_per_batch=batch)
+            wf.set_option(11, pipe)
+            wf.allocate(w, h)
+            fs = bundled_view(bundled, w, h, frames=1)
+            fs["samples"] = 0
+            f = fs.copy()
+            imgs = []
+            for k, spp in enumerate((2, 3, 1, 2, 4)):
+                wf.invoke(f, spp=spp, max_bounces=4, wait=False)
+                f["frames"] += spp
+                f["samples"] += spp
+                if k == 0:
+                    imgs.append(wf.read_image())                       # between two calls in flight
+                if k == 2:
+                    rays = np.array([[0, 2, 15, 0.01, 0.05, -1.0]], np.float32)
+                    assert wf.trace_closest(rays)["tri"][0] >= 0       # a query on the context's stream, which shares the first set's control block
+            imgs.append(wf.read_image())
+            st = wf.stats()
+            counters = tuple(st[k] for k in ("paths", "extend_rays", "shadow_rays", "extend_steps", "extend_tris", "shadow_steps", "shadow_tris"))
+            assert st["stack_overflows"] == 0
+            f["samples"] = 0                                           # FrameState.Samples == 0: the accumulation starts over, two calls deep
+            wf.invoke(f, spp=2, max_bounces=4, wait=False)
+            f["frames"] += 2
+            f["samples"] += 2
+            wf.invoke(f, spp=2, max_bounces=4, wait=False)
+            imgs.append(wf.read_image())
+            wf.allocate(96, 64)                                        # a resize with nothing waited for
+            wf.invoke(bundled_view(bundled, 96, 64, frames=3), spp=3, max_bounces=4, wait=False)
+            wf.invoke(bundled_view(bundled, 96, 64, frames=6), spp=1, max_bounces=4, wait=False)
+            imgs.append(wf.read_image())
+            got[(pipe, batch)] = (imgs, counters)
+            wf.close()
+    ref_imgs, ref_counters = got[(0, 0)]
+    for key, (imgs, counters) in got.items():
+        assert counters == ref_counters, key
+        for a, b in zip(imgs, ref_imgs):
+            assert np.array_equal(bits(a), bits(b)), key
+    fs = bundled_view(bundled, w, h, frames=1)
+    osum, _ = bundled.render(ob.render_state(w, h), fs, ob.path_config(4, 1, 1), 2)
+    assert np.array_equal(bits(ref_imgs[0]), bits(osum / np.float32(2)))
+
+
 def test_full_size_frame_properties(pa, ob, bundled):
     """The headline configuration at full size (1920x1080, 16 spp, 4 bounces, NEE), through properties that need no
     CPU render: the image is the same bits for 16 samples in one batch, in batches of 5, and as 4 + 12 over two calls;
