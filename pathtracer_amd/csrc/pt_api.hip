@@ -896,18 +896,25 @@ static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32
         const int rs = ensureSecondLane(c);
         if (rs != PT_OK) return rs;
         const uint32_t need = c->slots * chooseBatch(c, (uint32_t)spp);
+        bool both = true;
         for (const LaneRef& each : {ownLane(c), secondLane(c)}) {
             if (need <= *each.capacity) continue;
             HIPCHECK(c, hipStreamSynchronize(each.stream));
             HIPCHECK(c, hipStreamSynchronize(c->stream));
             const int ra = allocQueues(c, each, need);
-            if (ra != PT_OK) return ra;
+            if (ra == PT_OK) continue;
+            if (each.d_ctl == c->d_ctl) return ra;
+            // no room for a second set of queues: the context goes on with one, as if the option were off
+            c->err.clear();
+            (void)hipGetLastError();   // (the failed allocation's error is not this call's)
+            c->pipeline_calls = 0;
+            both = false;
         }
-        L = c->lane1_next ? secondLane(c) : ownLane(c);
+        L = both ? (c->lane1_next ? secondLane(c) : ownLane(c)) : inlineLane(c);
         // a call that finds the other set idle (a host that waits for every frame) has nobody to fill its tails: it gets the
         // connect stream, as a call on the context's stream does
         hipEvent_t const other = c->lane1_next ? c->ev_done0 : c->lane1.ev_done;
-        if (other == nullptr || hipEventQuery(other) != hipErrorNotReady) {
+        if (both && (other == nullptr || hipEventQuery(other) != hipErrorNotReady)) {
             L.stream_connect = c->stream_connect;
             L.ev_shaded = c->ev_shaded;
             L.ev_connected = c->ev_connected;
