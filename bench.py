@@ -404,8 +404,8 @@ def free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="bundled", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--spp", type=int, default=0)
