@@ -12,7 +12,7 @@ def main():
     root = sys.argv[1]
     names = [("c2 (default)", "bundled"), ("c1", "c1"), ("c3", "c3"), ("c4", "c4"), ("c5", "c5")]
     print("# Every BASELINE.json configuration on one MI355X\n")
-    print("`python bench.py --workload <name> --steps 3 --warmup 1` (this table: `tools/make_configs_md.py`), one GPU, scene and queues resident in HBM.")
+    print("`python bench.py --workload <name> --steps 3 --warmup 1` (20 steps for c1, the defaults for c2; `tools/run_cfgs.sh`; this table: `tools/make_configs_md.py`), one GPU, scene and queues resident in HBM.")
     print("c4 and c5 use synthetic stand-ins of the named triangle counts; their lines are the single-GPU leg of the 8-GPU configurations (every rank holds")
     print("the whole scene and traces its own tiles).  Roofs: vmem = vector-memory return rate for wave-coalesced lines (39,322 GB/s nominal; the per-lane record fetch of a traversal step is served at a quarter of it), valu = vector-ALU issue")
     print("(39.3 T lane-op/s), hbm = 8,000 GB/s; the bound named is the roof the extend kernel sits closest to.\n")
@@ -31,7 +31,7 @@ def main():
         print(f"| {label} | {c['workload']} | {c['triangles']} | {d['ms_per_step']:.2f} | {d['value']:.0f} | {a['extend_mrays_per_s']:.0f} | {a['bounce_extend_mrays_per_s']:.0f} | "
               f"{r['bvh_steps_per_ray']:.2f} | {r['tri_tests_per_ray']:.2f} | {a['bound']} | {a['frac']:.2f} | {fr['vmem']:.2f} | {fr['valu']:.2f} | {fr['hbm']:.3f} | "
               f"{r['frac']:.2f} ({r['bound']}) | {fmt(cpu.get('value'))} | {fmt(cpu.get('single_thread_value'))} |")
-    print("\nc1 is one sample of a 512x512 frame (0.26M paths): the frame is launch- and tail-bound, not traversal-bound.")
+    print("\nc1 is one sample of a 512x512 frame (0.26M paths): two traversal launches that each last as long as their longest ray (about 115 us); its rate is what two such frames in flight reach.")
 
 
 if __name__ == "__main__":
