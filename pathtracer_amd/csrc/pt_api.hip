@@ -195,6 +195,9 @@ void freeScene(pt_ctx* c) {
     c->sc = DevScene{};
 }
 
+#ifndef PT_PIPELINE_MAX_PATHS
+#define PT_PIPELINE_MAX_PATHS (64ull << 20)   // calls of more paths than this are traced on the context's stream, one at a time
+#endif
 #define PT_BYTES_PER_PATH 176u   // eleven 16-byte queue columns (allocQueues)
 int allocQueues(pt_ctx* c, const LaneRef& L, uint32_t capacity) {
     std::vector<void*>& qmem = *L.qmem;
@@ -888,7 +891,7 @@ static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32
     // Calls of up to 64M paths alternate between the two sets of streams and queues (11 GB each at most), so that two consecutive
     // frames are in flight together; larger calls are long enough for their tails not to matter and take the context's own set.
     // With per-stage timing the stages of a call have the GPU to themselves.
-    const bool eligible = c->pipeline_calls != 0 && c->cfg.stage_timing != 1 && (uint64_t)c->slots * chooseBatch(c, (uint32_t)spp) <= (64ull << 20);
+    const bool eligible = c->pipeline_calls != 0 && c->cfg.stage_timing != 1 && (uint64_t)c->slots * chooseBatch(c, (uint32_t)spp) <= PT_PIPELINE_MAX_PATHS;
     LaneRef L = inlineLane(c);
     if (eligible) {
         // both sets are made ready by the first call that could use them: the second set's queues are not allocated in the middle
