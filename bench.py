@@ -39,7 +39,7 @@ WORKLOADS = {
     "c1": ("bundled scene, 512x512, 1 spp, primary + 1 bounce, no NEE (the reference's own setting)", 512, 512, 1, 2, 0),
     "c3": ("synthetic 1M-triangle random soup + SAH BVH, 1920x1080, 64 spp, 4 bounces, diffuse only, NEE", 1920, 1080, 64, 4, 1),
     "c4": ("bundled recipe + 19 bunnies (259,600 triangles, Sponza-scale), 3840x2160, 256 spp in steps of 32, 4 bounces, NEE", 3840, 2160, 32, 4, 1),
-    "c5": ("4,026 instanced bunnies flattened (20.0M triangles), 3840x2160, 1024 spp in steps of 8, 8 bounces, NEE", 3840, 2160, 8, 8, 1),
+    "c5": ("4,026 instanced bunnies flattened (20.0M triangles), 3840x2160, 1024 spp in steps of 32, 8 bounces, NEE", 3840, 2160, 32, 8, 1),
 }
 
 # Vector memory.  A CU's texture path returns 64 bytes per clock when the lanes of a wave instruction cover whole cache lines
@@ -404,8 +404,8 @@ def free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="bundled", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--spp", type=int, default=0)

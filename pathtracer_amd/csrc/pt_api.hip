@@ -121,7 +121,8 @@ struct pt_ctx {
     int inst_mode = 0, fit_inst = 4;
     void *d_iquads = nullptr, *d_ibig = nullptr, *d_itris = nullptr, *d_iinst = nullptr, *d_built_of = nullptr;
     uint64_t local_pixels = 0;
-    int grid_extend = 0, grid_connect = 0, grid_shade = 0, fit_extend = 1, fit_connect = 1;
+    int grid_extend = 0, grid_connect = 0, grid_shade = 0, grid_shade_small = 0, fit_extend = 1, fit_connect = 1;
+    bool traverse_blocks_set = false;   // PT_OPT_TRAVERSE_BLOCKS_PER_CU was given: it then holds for every call
     void* scratch_dev = nullptr;   // this device's copy of the fixed staging array (pt_trace_closest_noalloc)
     // A second set of streams, events, control block and queues.  Consecutive render calls of moderate size alternate between the
     // context's first set and this one: every bounce of a frame ends in a tail of a few long rays during which most of the chip idles,
@@ -151,6 +152,9 @@ struct LaneRef {
     std::vector<void*>* qmem;
     uint32_t* capacity;
     bool hop;
+    // the call shares the GPU with another frame's kernels: its traversal grids leave room on every CU and its shade stage runs
+    // in small blocks that fit into that room (renderBatches)
+    bool shared = false;
 };
 // the first set on its own traversal stream (calls that may overlap with their neighbours)
 static LaneRef ownLane(pt_ctx* c) {
@@ -195,10 +199,10 @@ void freeScene(pt_ctx* c) {
     c->sc = DevScene{};
 }
 
-#ifndef PT_PIPELINE_MAX_PATHS
-#define PT_PIPELINE_MAX_PATHS (64ull << 20)   // calls of more paths than this are traced on the context's stream, one at a time
-#endif
 #define PT_BYTES_PER_PATH 176u   // eleven 16-byte queue columns (allocQueues)
+#ifndef PT_PIPELINE_MAX_PATHS
+#define PT_PIPELINE_MAX_PATHS (64ull << 20)   // batches of more paths than this are traced on the context's stream, one at a time
+#endif
 int allocQueues(pt_ctx* c, const LaneRef& L, uint32_t capacity) {
     std::vector<void*>& qmem = *L.qmem;
     Queues& q = *L.q;
@@ -560,8 +564,10 @@ static int impl_create_single(const pt_config* cfg, pt_ctx** out) {
     c->fit_connect = perCu;
     perCu = std::min(perCu, 7);
     c->grid_connect = c->num_cu * perCu;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_shade, PT_SHADE_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_shade<PT_SHADE_BLOCK>, PT_SHADE_BLOCK, 0) != hipSuccess || perCu < 1) perCu = 2;
     c->grid_shade = c->num_cu * perCu;   // one resident round: the kernel strides over the queue
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_shade<PT_SHADE_BLOCK_SMALL>, PT_SHADE_BLOCK_SMALL, 0) != hipSuccess || perCu < 1) perCu = 6;
+    c->grid_shade_small = c->num_cu * perCu;
     *out = c;
     return PT_OK;
 }
@@ -609,6 +615,7 @@ int pt_set_option(pt_ctx* c, int32_t key, int32_t value) {
             if (value < 0 || value > 16) FAIL(c, PT_E_INVALID_ARG, "traverse blocks per CU %d", value);
             c->grid_extend = c->num_cu * std::min(value ? value : 7, c->fit_extend);
             c->grid_connect = c->num_cu * std::min(value ? value : 7, c->fit_connect);
+            c->traverse_blocks_set = true;
             break;
         case PT_OPT_REFILL_PRIMARY: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_primary = value; c->refill_primary_set = true; break;
         case PT_OPT_REFILL_BOUNCE: if (value < 1 || value > 64) FAIL(c, PT_E_INVALID_ARG, "refill threshold %d", value); c->refill_bounce = value; c->refill_bounce_set = true; break;
@@ -723,13 +730,22 @@ static bool largeWalk(const pt_ctx* c) { return c->large_tree && walkMode(c) != 
         }                                                                                                               \
     } while (0)
 
-// the persistent grids fill the chip: as many blocks as fit (the instanced kernels need more registers, fewer fit)
-static int traverseGrid(const pt_ctx* c, int grid) { return walkMode(c) == PT_WALK_INST ? std::min(grid, c->num_cu * c->fit_inst) : grid; }
+// The persistent grids fill the chip: as many blocks as fit (the instanced kernels need more registers, fewer fit).  A frame that
+// shares the GPU with another one launches four blocks per CU instead: two frames' traversal grids together still fill every CU,
+// and beside one of them there is room (registers for two more waves per SIMD) for the other frame's shade and generate blocks, so
+// the stage that is bound by memory runs under the stage that is bound by instruction issue (1080p x 16 spp frames back to back:
+// 7.30 -> 6.92 ms; five blocks leave room for one wave per SIMD only and measure no gain, three cost the traversal too much).
+#define PT_SHARED_BLOCKS_PER_CU 4
+static int traverseGrid(const pt_ctx* c, const LaneRef& L, int grid) {
+    if (walkMode(c) == PT_WALK_INST) grid = std::min(grid, c->num_cu * c->fit_inst);
+    if (L.shared && !c->traverse_blocks_set) grid = std::min(grid, c->num_cu * PT_SHARED_BLOCKS_PER_CU);
+    return grid;
+}
 static void launchExtend(pt_ctx* c, const LaneRef& L, bool stats, int cur, uint32_t refillMin) {
-    PT_LAUNCH_WALK(k_extend, stats, walkMode(c), dim3(traverseGrid(c, c->grid_extend)), dim3(PT_BLOCK), L.stream, c->sc, *L.q, L.d_ctl, cur, refillMin);
+    PT_LAUNCH_WALK(k_extend, stats, walkMode(c), dim3(traverseGrid(c, L, c->grid_extend)), dim3(PT_BLOCK), L.stream, c->sc, *L.q, L.d_ctl, cur, refillMin);
 }
 static void launchConnect(pt_ctx* c, const LaneRef& L, bool stats, int cur, hipStream_t on) {
-    PT_LAUNCH_WALK(k_connect, stats, walkMode(c), dim3(traverseGrid(c, c->grid_connect)), dim3(PT_BLOCK), on, c->sc, *L.q, L.d_ctl, cur, bounceRefill(c));
+    PT_LAUNCH_WALK(k_connect, stats, walkMode(c), dim3(traverseGrid(c, L, c->grid_connect)), dim3(PT_BLOCK), on, c->sc, *L.q, L.d_ctl, cur, bounceRefill(c));
 }
 static void launchTrace(pt_ctx* c, bool anyhit, const TraceSource& src, int n) {
     PT_LAUNCH_WALK(k_trace, anyhit, walkMode(c), dim3(launchGrid((uint32_t)n)), dim3(PT_BLOCK), c->stream, c->sc, src, n, c->d_ctl);
@@ -765,7 +781,9 @@ static void freeSecondLane(pt_ctx* c) {
     if (l.stream) { (void)hipStreamDestroy(l.stream); l.stream = nullptr; }
 }
 
-static int renderBatches(pt_ctx* c, const LaneRef& L, const HostFrameState& fs, int32_t spp, int32_t max_bounces, bool generate_only) {
+// The batches of one call, batch k on lanes[k % n_lanes]: with two sets of queues neighbouring batches are in flight together, and their
+// planes still enter the accumulator in batch order (on the context's stream), so the image does not depend on the number of sets.
+static int renderBatches(pt_ctx* c, const LaneRef* lanes, uint32_t n_lanes, uint32_t batch, const HostFrameState& fs, int32_t spp, int32_t max_bounces, bool generate_only) {
     RenderParams rp{};
     rp.width = c->width;
     rp.height = c->height;
@@ -779,9 +797,12 @@ static int renderBatches(pt_ctx* c, const LaneRef& L, const HostFrameState& fs, 
     rp.nee = c->cfg.nee;
     const bool stats = c->cfg.traversal_stats != 0;
 
-    const uint32_t batch = generate_only ? 1u : chooseBatch(c, (uint32_t)spp);
+    if (generate_only) batch = 1u;
     const uint32_t need = c->slots * batch;
-    if (need > *L.capacity) {
+    const uint32_t n_batches = ((uint32_t)spp + batch - 1u) / batch;
+    for (uint32_t k = 0; k < std::min(n_lanes, n_batches); k++) {
+        const LaneRef& L = lanes[k];
+        if (need <= *L.capacity) continue;
         // the set's queues are replaced: whatever still reads them (its own streams; the accumulation of its planes, which runs on
         // the context's stream) has to be through
         HIPCHECK(c, hipStreamSynchronize(L.stream));
@@ -791,9 +812,11 @@ static int renderBatches(pt_ctx* c, const LaneRef& L, const HostFrameState& fs, 
         if (rc != PT_OK) return rc;
     }
     if (c->slots == 0) return PT_OK;
-    const Queues& q = *L.q;
 
-    for (uint32_t s0 = 0; s0 < (uint32_t)spp; s0 += batch) {
+    uint32_t turn = 0;
+    for (uint32_t s0 = 0; s0 < (uint32_t)spp; s0 += batch, turn++) {
+        const LaneRef& L = lanes[turn % n_lanes];
+        const Queues& q = *L.q;
         const uint32_t ns = std::min(batch, (uint32_t)spp - s0);
         const uint32_t total = c->slots * ns;
         rp.frames0 = (uint32_t)fs.frames + s0;
@@ -839,7 +862,8 @@ static int renderBatches(pt_ctx* c, const LaneRef& L, const HostFrameState& fs, 
             if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(L.stream, L.ev_connected, 0)); connectPending = false; }
             {
                 StageTimer t(c, 2, L.stream);
-                hipLaunchKernelGGL(k_shade, dim3(c->grid_shade), dim3(PT_SHADE_BLOCK), 0, L.stream, c->sc, rp, q, L.d_ctl, cur);
+                if (L.shared) hipLaunchKernelGGL(k_shade<PT_SHADE_BLOCK_SMALL>, dim3(c->grid_shade_small), dim3(PT_SHADE_BLOCK_SMALL), 0, L.stream, c->sc, rp, q, L.d_ctl, cur);
+                else hipLaunchKernelGGL(k_shade<PT_SHADE_BLOCK>, dim3(c->grid_shade), dim3(PT_SHADE_BLOCK), 0, L.stream, c->sc, rp, q, L.d_ctl, cur);
                 c->host_stats.shade_launches++;
             }
             if (rp.nee && c->sc.n_lights > 0) {
@@ -888,17 +912,21 @@ static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32
         c->samples_accumulated = 0;
     }
     HIPCHECK(c, hipEventRecord(c->ev_begin, c->stream));
-    // Calls of up to 64M paths alternate between the two sets of streams and queues (11 GB each at most), so that two consecutive
-    // frames are in flight together; larger calls are long enough for their tails not to matter and take the context's own set.
-    // With per-stage timing the stages of a call have the GPU to themselves.
-    const bool eligible = c->pipeline_calls != 0 && c->cfg.stage_timing != 1 && (uint64_t)c->slots * chooseBatch(c, (uint32_t)spp) <= PT_PIPELINE_MAX_PATHS;
-    LaneRef L = inlineLane(c);
+    // Batches of up to 64M paths alternate between the two sets of streams and queues (11 GB each at most) — the batches of one call
+    // and consecutive calls of one batch each alike: two are in flight together, fill each other's tails, and the shade stage of one
+    // runs under the traversal of the other.  Larger batches are long enough for their tails not to matter and take the context's
+    // own set (halving them to have two in flight measured +1 % on a 265M-path call of 4 bounces and -4 % on one of 8 bounces).
+    // With per-stage timing the stages of a call have the GPU to themselves, on the context's stream.
+    uint32_t batch = chooseBatch(c, (uint32_t)spp);
+    const bool eligible = c->pipeline_calls != 0 && c->cfg.stage_timing != 1 && (uint64_t)c->slots * batch <= PT_PIPELINE_MAX_PATHS;
+    LaneRef lanes[2] = {inlineLane(c), inlineLane(c)};
+    uint32_t n_lanes = 1;
     if (eligible) {
         // both sets are made ready by the first call that could use them: the second set's queues are not allocated in the middle
         // of a run of frames
         const int rs = ensureSecondLane(c);
         if (rs != PT_OK) return rs;
-        const uint32_t need = c->slots * chooseBatch(c, (uint32_t)spp);
+        const uint32_t need = c->slots * batch;
         bool both = true;
         for (const LaneRef& each : {ownLane(c), secondLane(c)}) {
             if (need <= *each.capacity) continue;
@@ -913,20 +941,31 @@ static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32
             c->pipeline_calls = 0;
             both = false;
         }
-        L = both ? (c->lane1_next ? secondLane(c) : ownLane(c)) : inlineLane(c);
-        // a call that finds the other set idle (a host that waits for every frame) has nobody to fill its tails: it gets the
-        // connect stream, as a call on the context's stream does
-        hipEvent_t const other = c->lane1_next ? c->ev_done0 : c->lane1.ev_done;
-        if (both && (other == nullptr || hipEventQuery(other) != hipErrorNotReady)) {
-            L.stream_connect = c->stream_connect;
-            L.ev_shaded = c->ev_shaded;
-            L.ev_connected = c->ev_connected;
+        if (both) {
+            const bool second_first = c->lane1_next;
+            lanes[0] = second_first ? secondLane(c) : ownLane(c);
+            lanes[1] = second_first ? ownLane(c) : secondLane(c);
+            n_lanes = 2;
+            const uint32_t n_batches = ((uint32_t)spp + batch - 1u) / batch;
+            hipEvent_t const other = second_first ? c->ev_done0 : c->lane1.ev_done;
+            if (n_batches >= 2u) {
+                lanes[0].shared = lanes[1].shared = true;
+            } else if (other == nullptr || hipEventQuery(other) != hipErrorNotReady) {
+                // a lone batch that finds the other set idle (a host that waits for every small frame) has nobody to fill its tails:
+                // it gets the connect stream, as a call on the context's stream does
+                lanes[0].stream_connect = c->stream_connect;
+                lanes[0].ev_shaded = c->ev_shaded;
+                lanes[0].ev_connected = c->ev_connected;
+            } else {
+                lanes[0].shared = true;
+            }
+            if (n_batches & 1u) c->lane1_next = !c->lane1_next;   // the next call starts on the set this one did not end on
         }
-        c->lane1_next = !c->lane1_next;
     }
-    int rc = renderBatches(c, L, fs, spp, max_bounces, false);
+    int rc = renderBatches(c, lanes, n_lanes, batch, fs, spp, max_bounces, false);
     if (rc != PT_OK) {
-        if (L.hop) (void)hipStreamSynchronize(L.stream);   // nothing of a failed call stays behind on a set's stream
+        for (uint32_t k = 0; k < n_lanes; k++)
+            if (lanes[k].hop) (void)hipStreamSynchronize(lanes[k].stream);   // nothing of a failed call stays behind on a set's stream
         return rc;
     }
     HIPCHECK(c, hipEventRecord(c->ev_end, c->stream));
@@ -1125,7 +1164,8 @@ static int impl_generate_rays(pt_ctx* c, const void* frame_state112, int32_t n, 
     HIPCHECK(c, hipSetDevice(c->cfg.device));
     HostFrameState fs;
     memcpy(&fs, frame_state112, sizeof(fs));
-    int rc = renderBatches(c, inlineLane(c), fs, 1, 1, true);
+    const LaneRef only = inlineLane(c);
+    int rc = renderBatches(c, &only, 1, 1, fs, 1, 1, true);
     if (rc != PT_OK) return rc;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     Ctl ctl;

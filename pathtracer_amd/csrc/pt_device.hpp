@@ -114,8 +114,6 @@ struct DevScene {
 // Counters and queue sizes shared by the stages of one context (device memory).
 struct Ctl {
     uint32_t count[2];        // live rays in the ping/pong path queues
-    uint32_t shadow_count[2]; // rays in the shadow queue, by the parity of the bounce that filled it (connect of one bounce may still be reading its
-                              // count while extend of the next bounce clears the other)
     uint32_t cursor_extend;   // next unclaimed ray of the running extend launch
     uint32_t cursor_connect;
     unsigned long long paths, extend_rays, shadow_rays, extend_steps, extend_tris, shadow_steps, shadow_tris, stack_overflows;
@@ -123,6 +121,10 @@ struct Ctl {
     unsigned long long special_rays;                               // rays that took the two-wide, NaN-rejecting walk
     unsigned long long unique_steps, unique_tris;                  // extend stage, instrumented builds: DISTINCT records fetched per wave instruction, summed
     unsigned long long shadow_occluded;                            // connect stage, instrumented builds: shadow rays that found an occluder
+    // rays in the shadow queue, by the parity of the bounce that filled it (connect of one bounce may still be reading its count while
+    // extend of the next bounce clears the other).  Far from count[]: every block of the shade stage adds to one of each per round,
+    // and two atomics on one cache line take turns where two on distant lines proceed side by side.
+    alignas(4096) uint32_t shadow_count[2];
 };
 
 // ------------------------------------------------ deterministic elementary fns

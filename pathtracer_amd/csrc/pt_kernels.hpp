@@ -312,10 +312,11 @@ __device__ __forceinline__ int pickLight(const DevScene& sc, float r) {
 // Dense output slots in two queues at once for the threads of the block with a / b set: wave ballots, a prefix
 // over the waves' counts in LDS, and ONE atomic per queue and block (a single counter word sustains only
 // ~90 atomics/us, so per-wave atomics would bound the whole stage).  All threads of the block must call it
-// together; `lds` holds 2 x (PT_SHADE_BLOCK / 64) counts and 2 bases, and callers alternate between two such areas
+// together; `lds` holds 2 x (BLOCK / 64) counts and 2 bases, and callers alternate between two such areas
 // from one call to the next, which is what makes two barriers enough.
+template <int BLOCK>
 __device__ __forceinline__ void blockAppend2(bool a, bool b, uint32_t* counterA, uint32_t* counterB, uint32_t* lds, uint32_t* slotA, uint32_t* slotB) {
-    constexpr uint32_t W = PT_SHADE_BLOCK / PT_WAVE;
+    constexpr uint32_t W = BLOCK / PT_WAVE;
     const unsigned long long maskA = __ballot(a), maskB = __ballot(b);
     const uint32_t lane = laneId(), wave = threadIdx.x / PT_WAVE;
     if (lane == 0) { lds[wave] = (uint32_t)__popcll(maskA); lds[W + wave] = (uint32_t)__popcll(maskB); }
@@ -337,11 +338,17 @@ __device__ __forceinline__ void blockAppend2(bool a, bool b, uint32_t* counterA,
 // survivors are appended to the other queue by wave-level ballot/prefix compaction.
 // 6 waves per SIMD (80 VGPRs, 12 bytes of scratch) = two resident 768-thread blocks per CU: 5 % faster than the 96 VGPRs
 // the compiler takes when left alone, and the larger block needs fewer appends to the one queue counter.
+// A second instantiation with 256-thread blocks is for frames that share the GPU with another frame's traversal: its blocks are one
+// wave per SIMD and fit beside four resident traversal waves, so this stage (bound by memory) runs under the other frame's extend
+// (bound by instruction issue) instead of waiting for its blocks to leave.  Alone it is slower than the large block (three times
+// the appends: 2.2 against 1.3 ms on a 1080p x 16 spp frame).
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 6
 #endif
-__global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc, RenderParams rp, Queues q, Ctl* ctl, int cur) {
-    __shared__ uint32_t s_append[2][2 * (PT_SHADE_BLOCK / PT_WAVE) + 2];
+#define PT_SHADE_BLOCK_SMALL 256
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc, RenderParams rp, Queues q, Ctl* ctl, int cur) {
+    __shared__ uint32_t s_append[2][2 * (BLOCK / PT_WAVE) + 2];
     const uint32_t n = ctl->count[cur];
     const int nxt = cur ^ 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -501,7 +508,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DevSce
             else if (addIt) q.plane[birth] = to4(from4(q.plane[birth]) + add);
         }
         uint32_t slotOut, sOut;
-        blockAppend2(survive, shadow, &ctl->count[nxt], &ctl->shadow_count[cur], s_append[it & 1u], &slotOut, &sOut);
+        blockAppend2<BLOCK>(survive, shadow, &ctl->count[nxt], &ctl->shadow_count[cur], s_append[it & 1u], &slotOut, &sOut);
         if (survive) {
             ntStore(&q.o[nxt][slotOut], make_float4(newO.x, newO.y, newO.z, __uint_as_float(birth)));
             ntStore(&q.d[nxt][slotOut], make_float4(newD.x, newD.y, newD.z, __uint_as_float(newFlags)));

@@ -32,6 +32,8 @@ def main():
               f"{r['bvh_steps_per_ray']:.2f} | {r['tri_tests_per_ray']:.2f} | {a['bound']} | {a['frac']:.2f} | {fr['vmem']:.2f} | {fr['valu']:.2f} | {fr['hbm']:.3f} | "
               f"{r['frac']:.2f} ({r['bound']}) | {fmt(cpu.get('value'))} | {fmt(cpu.get('single_thread_value'))} |")
     print("\nc1 is one sample of a 512x512 frame (0.26M paths): two traversal launches that each last as long as their longest ray (about 115 us); its rate is what two such frames in flight reach.")
+    print("c5's tree and triangles (1.7 GB) are beyond every cache: its bounce launches read 4.8-6.2 TB/s at L2's memory side (0.6-0.78 of the HBM peak, every request a 128-byte line) "
+          "with the vector ALUs 0.7-0.9 busy (`profiles/r03_c5_extend_per_launch.txt`); the `hbm frac` column prices only the bytes a launch cannot avoid (ray records and one pass over the scene).")
 
 
 if __name__ == "__main__":
