@@ -218,7 +218,9 @@ int pt_build_scene_instanced(pt_ctx* ctx, const void* materials, int32_t n_mat, 
 
 /* Runtime switches: key is one of PT_OPT_*; takes effect at the next pt_render. */
 enum { PT_OPT_NEE = 1, PT_OPT_RNG_MODE = 2, PT_OPT_TRAVERSAL_STATS = 3, PT_OPT_STAGE_TIMING = 4, PT_OPT_SAMPLES_PER_BATCH = 5,
-       PT_OPT_TRAVERSE_BLOCKS_PER_CU = 6 /* resident 256-thread blocks per CU of the traversal kernels; 0 = the default (at most 7) */,
+       PT_OPT_TRAVERSE_BLOCKS_PER_CU = 6 /* resident 256-thread blocks per CU of the traversal kernels; 0 = the default (at most 7).
+                                            Once set it holds for every call; left alone, a call that shares the GPU with another
+                                            frame launches four per CU (PT_OPT_PIPELINE_CALLS) */,
        PT_OPT_REFILL_PRIMARY = 7 /* idle lanes (1..64) a traversal wave collects before it fetches new camera rays; default 48 */,
        PT_OPT_REFILL_BOUNCE = 8 /* the same for bounce and shadow rays; default 40 */,
        PT_OPT_QUANTIZED = 9 /* which node records the traversal kernels walk: 0 the exact 128-byte records, 1 the 64-byte records
@@ -226,9 +228,11 @@ enum { PT_OPT_NEE = 1, PT_OPT_RNG_MODE = 2, PT_OPT_TRAVERSAL_STATS = 3, PT_OPT_S
                                same), 2 (default) the 64-byte records for trees that exceed the L2 caches */,
        PT_OPT_INSTANCED = 10 /* 1: walk the instances of a scene installed by pt_build_scene_instanced (0, the default, and every
                                 scene installed another way: the flattened triangles) */,
-       PT_OPT_PIPELINE_CALLS = 11 /* 1 (default): consecutive pt_render calls of up to 64M paths are traced on two alternating sets of
-                                     streams and queues, so that two frames are in flight together and fill each other's tails; their
-                                     samples still enter the accumulator in call order, on the context's stream.  0: one set */ };
+       PT_OPT_PIPELINE_CALLS = 11 /* 1 (default): batches of up to 64M paths (consecutive pt_render calls, and the batches of one call)
+                                     are traced on two alternating sets of streams and queues, so that two frames are in flight
+                                     together, fill each other's tails, and one's shade stage runs under the other's traversal (a call
+                                     that finds the other set busy launches smaller traversal grids and shade blocks to that end);
+                                     their samples still enter the accumulator in call order, on the context's stream.  0: one set */ };
 int pt_set_option(pt_ctx* ctx, int32_t key, int32_t value);
 
 /* ---- multi-GPU tiles, one process per GPU --------------------------------------

@@ -54,13 +54,13 @@ def main():
     tag, run, bench_name = sys.argv[1], sys.argv[2], sys.argv[3]
     out, prof = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
     previous = json.load(open(os.path.join(prof, "traffic.json"))) if os.path.exists(os.path.join(prof, "traffic.json")) else {}
-    traffic = {}
+    traffic = dict(previous)   # entries of other workloads (config 5's passes are collected by hand) stay
     for w, args in (("bundled", ""), ("c3", " --workload c3 --steps 1")):
         summary = os.path.join(out, f"{run}_pmc_{w}_summary.txt")
         shutil.copy(summary, os.path.join(prof, f"{tag}_bench_{w}_pmc.txt"))
         # the headline scene is walked through the exact records, the soup (a tree beyond L2) through the quantised ones
         kernel = "void k_extend<false, 1>" if w == "c3" else "void k_extend<false, 0>"
-        traffic[w] = traffic_entry(counters(summary, kernel), f"profiles/{tag}_bench_{w}_pmc.txt", "python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-secondary" + args)
+        traffic[w] = traffic_entry(counters(summary, kernel), f"profiles/{tag}_bench_{w}_pmc.txt", "python3 bench.py --steps 2 --warmup 0 --no-pipeline --no-cpu-baseline --no-secondary" + args)
         stats = sorted(glob.glob(os.path.join(out, f"{run}_pmc_{w}", "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
         shutil.copy(stats[-1], os.path.join(prof, f"{tag}_bench_{w}_kernel_stats.csv"))
     json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
@@ -68,7 +68,7 @@ def main():
     shutil.copy(os.path.join(out, bench_name), os.path.join(cfg, "bundled.json"))
     for w in ("bundled", "c1", "c3", "c4", "c5"):
         d = json.load(open(os.path.join(cfg, w + ".json")))
-        if w in traffic:    # the line was printed with the previous round's traffic.json
+        if w in traffic and w in ("bundled", "c3"):    # the line was printed with the previous round's traffic.json
             d["roofline"]["traffic"] = traffic[w]["extend_hbm_bytes_per_launch"]
             d["roofline"]["traffic_source"] = traffic[w]["source"] + " (committed PMC passes of the same command, not measured by this run)"
             # the line's cross-check was printed against the previous passes' instruction count: restate it against these
