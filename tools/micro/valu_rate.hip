@@ -104,6 +104,10 @@ __global__ void __launch_bounds__(256) k(int iters, float seed, float* out, unsi
                 if (KIND == 33) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u7) : "v"(ub));
                 else asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(u7) : "v"(ub));
             }
+            else if (KIND == 35) { ALLU("v_or_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1") }
+            else if (KIND == 36) { ALLU("v_cvt_f32_u32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1") }
+            else if (KIND == 37) { ALLU("v_lshrrev_b32 %0, 1, %0") }
+            else if (KIND == 38) { ALLU("v_and_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0") }
             else if (KIND == 19) {   // selects on a fixed SGPR pair
 #define S(i) asm volatile("v_cndmask_b32 %0, %0, %1, s[22:23]" : "+v"(u##i) : "v"(ub));
                 S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
@@ -190,6 +194,10 @@ int main() {
         run<29>("v_bfe_u32", cus, w, out, clocks);
         run<16>("v_cmp e64", cus, w, out, clocks);
         run<15>("cmp,cndmask", cus, w, out, clocks);
+        run<37>("v_lshrrev_b32", cus, w, out, clocks);
+        run<35>("v_or_b32 sdwa", cus, w, out, clocks);
+        run<38>("v_and_b32 sdwa", cus, w, out, clocks);
+        run<36>("v_cvt_f32_u32 sdwa", cus, w, out, clocks);
     }
     return 0;
 }
