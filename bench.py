@@ -478,15 +478,19 @@ def main():
 
     counted, staged = run.instrumented()
     stage_ms = {k: staged["ms_" + k] for k in ("generate", "extend", "shade", "connect")}
-    wf.set_option(4, 2)   # the timed steps bracket only the extend launches (every pair of events costs stream time)
+    # the timed steps bracket only the extend launches (every pair of events costs stream time), and not even those when the launch
+    # duration is taken from the frames rendered one at a time afterwards
+    pipelined = not getattr(args, "no_pipeline", False)
+    wf.set_option(4, 0 if pipelined else 2)
     dt, st = timed_steps(run, args.steps, args.warmup, sync_all)
     # The timed steps run two frames in flight (consecutive pt_render calls overlap): an extend launch then shares the GPU with the
     # other frame's kernels, and the span between the events around it includes the time its blocks wait to be placed.  The kernel's
     # own launch duration — what the roofline divides by, and what rocprofv3's kernel statistics of this command show — is taken from
     # a few more frames with one frame in flight (connect of a bounce still beside extend of the next, as a lone frame runs).
     st_span = st
-    if not getattr(args, "no_pipeline", False):
+    if pipelined:
         wf.set_option(11, 0)
+        wf.set_option(4, 2)
         _, st = timed_steps(run, min(args.steps, 3), 0, sync_all)
         wf.set_option(11, 1)
 
@@ -518,8 +522,7 @@ def main():
         roof["primary_extend_mrays_per_s"] = st["paths"] / max(1e-9, st["ms_extend_primary"] * 1e-3) / 1e6
         if st_span is not st:
             roof["launch_timing"] = ("HIP events around the extend launches of frames rendered one at a time after the timed steps; in the timed steps two frames are "
-                                     "in flight and the same events span %.3f ms per launch, queueing behind the other frame included"
-                                     % (st_span["ms_extend"] / max(1, st_span["extend_launches"])))
+                                     "in flight, a launch shares the GPU with the other frame's kernels, and no events are recorded")
         overridden = args.spp or args.width or args.height or args.bounces
         out = {
             "metric": "Mrays/s (primary+bounce+shadow rays traced)", "value": (extend_rays + shadow_rays) / dt / 1e6, "unit": "Mrays/s",
