@@ -744,6 +744,10 @@ static int traverseGrid(const pt_ctx* c, const LaneRef& L, int grid) {
 static void launchExtend(pt_ctx* c, const LaneRef& L, bool stats, int cur, uint32_t refillMin) {
     PT_LAUNCH_WALK(k_extend, stats, walkMode(c), dim3(traverseGrid(c, L, c->grid_extend)), dim3(PT_BLOCK), L.stream, c->sc, *L.q, L.d_ctl, cur, refillMin);
 }
+// extend of the queue `cur` and, in the same grid, connect of the shadow rays the bounce before left (k_connect_extend)
+static void launchConnectExtend(pt_ctx* c, const LaneRef& L, bool stats, int cur, uint32_t refillMin) {
+    PT_LAUNCH_WALK(k_connect_extend, stats, walkMode(c), dim3(traverseGrid(c, L, c->grid_extend)), dim3(PT_BLOCK), L.stream, c->sc, *L.q, L.d_ctl, cur, refillMin, bounceRefill(c));
+}
 static void launchConnect(pt_ctx* c, const LaneRef& L, bool stats, int cur, hipStream_t on) {
     PT_LAUNCH_WALK(k_connect, stats, walkMode(c), dim3(traverseGrid(c, L, c->grid_connect)), dim3(PT_BLOCK), on, c->sc, *L.q, L.d_ctl, cur, bounceRefill(c));
 }
@@ -845,6 +849,13 @@ static int renderBatches(pt_ctx* c, const LaneRef* lanes, uint32_t n_lanes, uint
         // kernels back (measured: 1 % from two frames in flight with a connect stream per set, 4.4 % without).
         const bool beside = c->cfg.stage_timing != 1 && L.stream_connect != nullptr;
         bool connectPending = false;
+        // A frame that shares the GPU traces the shadow rays of every bounce but the last inside the next bounce's extend launch
+        // (k_connect_extend): three launches fewer in its chain, and no connect launch that ends on a few long shadow rays (headline
+        // +0.6 %, the 8-spp soup frame +2 %).  Large calls keep the stages apart (their connect runs beside the next extend anyway;
+        // fused, 265M-path calls measured -0.9 % on the bundled-like 4K scene, +2 % and +1 % on the two large trees), and so does
+        // per-stage timing.
+        const bool fuse = L.shared && c->cfg.stage_timing != 1;
+        bool connectDeferred = false;
         // a way out of this loop with a connect still running on its stream (a failed call below) waits for it: everything else
         // in the library orders itself after the context's main stream only
         struct Join {
@@ -856,7 +867,10 @@ static int renderBatches(pt_ctx* c, const LaneRef* lanes, uint32_t n_lanes, uint
             rp.last_bounce = (b == max_bounces - 1) ? 1 : 0;
             {
                 StageTimer t(c, b == 0 ? 4 : 1, L.stream);
-                launchExtend(c, L, stats, cur, (uint32_t)(b == 0 ? ((largeWalk(c) && !c->refill_primary_set) ? 32 : c->refill_primary) : bounceRefill(c)));
+                const uint32_t refill = (uint32_t)(b == 0 ? ((largeWalk(c) && !c->refill_primary_set) ? 32 : c->refill_primary) : bounceRefill(c));
+                if (connectDeferred) launchConnectExtend(c, L, stats, cur, refill);
+                else launchExtend(c, L, stats, cur, refill);
+                connectDeferred = false;
                 c->host_stats.extend_launches++;
             }
             if (connectPending) { HIPCHECK(c, hipStreamWaitEvent(L.stream, L.ev_connected, 0)); connectPending = false; }
@@ -866,7 +880,10 @@ static int renderBatches(pt_ctx* c, const LaneRef* lanes, uint32_t n_lanes, uint
                 else hipLaunchKernelGGL(k_shade<PT_SHADE_BLOCK>, dim3(c->grid_shade), dim3(PT_SHADE_BLOCK), 0, L.stream, c->sc, rp, q, L.d_ctl, cur);
                 c->host_stats.shade_launches++;
             }
-            if (rp.nee && c->sc.n_lights > 0) {
+            if (rp.nee && c->sc.n_lights > 0 && fuse && b + 1 < max_bounces) {
+                connectDeferred = true;
+                c->host_stats.connect_launches++;
+            } else if (rp.nee && c->sc.n_lights > 0) {
                 StageTimer t(c, 3, L.stream);
                 hipStream_t on = L.stream;
                 if (beside) {

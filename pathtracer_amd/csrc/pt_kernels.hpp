@@ -216,6 +216,69 @@ __global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_W
     if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
 }
 
+// ---------------------------------------------------- connect + extend in one launch
+// The shadow rays of bounce b and the path rays of bounce b + 1 in one grid: every wave first takes shadow rays until that queue is dry,
+// then path rays.  The two stages only meet the shade launches around them (see k_connect), so they may share a launch, and the few
+// long shadow rays that would end a connect launch of their own finish under the path rays of the waves that are through.
+template <bool STATS, int MODE>
+__global__ void __launch_bounds__(PT_BLOCK, MODE == PT_WALK_INST ? PT_TRAVERSE_WAVES : ((MODE == PT_WALK_QUANT || PT_POOL != 0) ? PT_TRAVERSE_WAVES + 1 : PT_TRAVERSE_WAVES))
+k_connect_extend(DevScene sc, Queues q, Ctl* ctl, int cur, uint32_t refillMin, uint32_t refillShadow) {
+    __shared__ uint2 lds_stack[(PT_BLOCK / PT_WAVE) * PT_STACK_LDS * PT_WAVE];
+    __shared__ unsigned long long lds_leafq[(PT_BLOCK / PT_WAVE) * PT_LEAFQ_WORDS];
+    uint2* lstack = lds_stack + (threadIdx.x / PT_WAVE) * (PT_STACK_LDS * PT_WAVE);
+    unsigned long long* leafq = lds_leafq + (threadIdx.x / PT_WAVE) * PT_LEAFQ_WORDS;
+    constexpr bool POOL = PT_POOL != 0 && MODE != PT_WALK_INST;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_pool[POOL ? PT_POOL_WORDS : 4];
+    if (POOL) {
+        if (threadIdx.x < 4) lds_pool[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    const uint32_t n = ctl->count[cur], nShadow = ctl->shadow_count[cur ^ 1];   // the shadow rays are those of the bounce before
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->count[cur ^ 1] = 0;
+        ctl->shadow_count[cur] = 0;
+        atomicAdd(&ctl->extend_rays, (unsigned long long)n);
+        atomicAdd(&ctl->shadow_rays, (unsigned long long)nShadow);
+    }
+    uint32_t overflow = 0;
+    {
+        uint32_t steps = 0, tris = 0;
+        ConnectSource src;
+        src.so = q.so;
+        src.sd = q.sd;
+        src.sc = q.sc;
+        src.plane = q.plane;
+        uint32_t sched[6] = {0, 0, 0, 0, 0, 0};
+        traverseWave<true, STATS, MODE, POOL>(sc, nShadow, &ctl->cursor_connect, lstack, leafq, src, &steps, &tris, &overflow, sched, refillShadow, &ctl->special_rays, lds_pool);
+        if (STATS) {
+            waveAdd64(&ctl->shadow_steps, steps);
+            waveAdd64(&ctl->shadow_tris, tris);
+            if (laneId() == 0) atomicAdd(&ctl->shadow_occluded, (unsigned long long)sched[5]);
+        }
+    }
+    {
+        uint32_t steps = 0, tris = 0;
+        ExtendSource src;
+        src.o = q.o[cur];
+        src.d = q.d[cur];
+        src.hit = q.hit;
+        uint32_t sched[6] = {0, 0, 0, 0, 0, 0};
+        traverseWave<false, STATS, MODE, POOL>(sc, n, &ctl->cursor_extend, lstack, leafq, src, &steps, &tris, &overflow, sched, refillMin, &ctl->special_rays, lds_pool);
+        if (STATS) {
+            waveAdd64(&ctl->extend_steps, steps);
+            waveAdd64(&ctl->extend_tris, tris);
+            if (laneId() == 0) {
+                atomicAdd(&ctl->sched_interior, (unsigned long long)sched[0]);
+                atomicAdd(&ctl->sched_leaf, (unsigned long long)sched[1]);
+                atomicAdd(&ctl->sched_refill, (unsigned long long)sched[2]);
+                atomicAdd(&ctl->unique_steps, (unsigned long long)sched[3]);
+                atomicAdd(&ctl->unique_tris, (unsigned long long)sched[4]);
+            }
+        }
+    }
+    if (__any(overflow != 0)) waveAdd64(&ctl->stack_overflows, overflow);
+}
+
 // --------------------------------------------------------------------- shade
 // shade.glsl:150-162
 __device__ __forceinline__ float schlick(f3 direction, f3 normal, float n1, float n2) {
