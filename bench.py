@@ -356,8 +356,13 @@ def secondary_soup(args, cost, steps=3):
     def sync_all():
         run.wf.synchronize()
 
-    run.wf.set_option(4, 2)   # the production schedule (events around the extend launches only), as the headline steps are timed
-    dt, st = timed_steps(run, steps, 1, sync_all)
+    # the production schedule (no events; over the quantised records connect of a bounce runs inside the next bounce's extend launch),
+    # as the headline steps are timed; then one frame with events around the extend launches, which also gives every stage launches of
+    # its own (connect beside the next extend on a second stream), for the launch durations the roofline divides by
+    run.wf.set_option(4, 0)
+    dt, st_run = timed_steps(run, steps, 1, sync_all)
+    run.wf.set_option(4, 2)
+    _, st = timed_steps(run, 1, 0, sync_all)
     # per-stage figures: from the one frame whose every stage was bracketed by events, stages back to back on one stream (in the timed
     # frames connect of a bounce runs beside extend of the next one, and an extend launch's events then span shared time)
     bounce_rays = staged["extend_rays"] - staged["paths"]
@@ -369,14 +374,15 @@ def secondary_soup(args, cost, steps=3):
     alone = traversal_roofline(counted, staged, kcost, run.n_quads, int(run.tris.size), committed_pmc("c3"), run.quant)
     out = {
         "workload": run.desc, "steps": steps, "ms_per_frame": dt / steps * 1e3,
-        "mrays_per_s": (st["extend_rays"] + st["shadow_rays"]) / dt / 1e6,
+        "mrays_per_s": (st_run["extend_rays"] + st_run["shadow_rays"]) / dt / 1e6,
         "extend_mrays_per_s": staged["extend_rays"] / max(1e-9, staged["ms_extend"] * 1e-3) / 1e6,
         "bounce_extend_mrays_per_s": bounce_rays / max(1e-9, bounce_ms * 1e-3) / 1e6,
         "primary_extend_mrays_per_s": staged["paths"] / max(1e-9, staged["ms_extend_primary"] * 1e-3) / 1e6,
         "connect_mrays_per_s": staged["shadow_rays"] / max(1e-9, staged["ms_connect"] * 1e-3) / 1e6,
         "stage_ms_per_frame": {k: staged["ms_" + k] for k in ("generate", "extend", "shade", "connect")},
-        "stage_ms_note": "stages back to back on one stream (one frame); ms_per_frame is the production schedule, connect beside the next extend",
-        "rays_per_frame": {"extend": st["extend_rays"] / steps, "bounce": bounce_rays, "shadow": st["shadow_rays"] / steps},
+        "stage_ms_note": "stages back to back on one stream (one frame); ms_per_frame is the production schedule, connect of a bounce inside the next bounce's extend launch; "
+                         "roofline: one more frame with events around its extend launches and connect beside the next extend on a second stream",
+        "rays_per_frame": {"extend": st_run["extend_rays"] / steps, "bounce": bounce_rays, "shadow": st_run["shadow_rays"] / steps},
         "shadow_bvh_steps_per_ray": counted["shadow_steps"] / max(1, counted["shadow_rays"]),
         "shadow_tri_tests_per_ray": counted["shadow_tris"] / max(1, counted["shadow_rays"]),
         "node_records": "quantised, 64 B" if run.quant else "exact, 128 B",

@@ -60,8 +60,10 @@ typedef struct pt_config {
     int32_t samples_per_batch;  /* samples traced concurrently; 0 = as many as give 256M paths per launch (176 bytes of device memory per path,
                                    at most a quarter of what is free); a number bounds the memory a render call takes */
     int32_t traversal_stats;    /* 1 = count BVH steps / triangle tests (slower instrumented kernels) */
-    int32_t stage_timing;       /* 1 = bracket every stage launch with events (pt_get_stats ms_*), 2 = the extend
-                                   launches only (a pair of events costs about 5 us of stream time) */
+    int32_t stage_timing;       /* 1 = bracket every stage launch with events (pt_get_stats ms_*), stages back to back on one stream;
+                                   2 = the extend launches only (a pair of events costs about 5 us of stream time).  With either,
+                                   every stage has launches of its own; with 0 the shadow rays of a bounce may be traced inside the
+                                   next bounce's extend launch */
     int32_t device_count;       /* GPUs behind this one context: devices device .. device + device_count - 1.  With more than one,
                                    the scene is replicated, the image's 8x8 pixel groups are dealt round-robin to the GPUs, and
                                    pt_read_image gathers the tiles to the first GPU with RCCL (grouped ncclSend / ncclRecv, once per

@@ -851,10 +851,11 @@ static int renderBatches(pt_ctx* c, const LaneRef* lanes, uint32_t n_lanes, uint
         bool connectPending = false;
         // A frame that shares the GPU traces the shadow rays of every bounce but the last inside the next bounce's extend launch
         // (k_connect_extend): three launches fewer in its chain, and no connect launch that ends on a few long shadow rays (headline
-        // +0.6 %, the 8-spp soup frame +2 %).  Large calls keep the stages apart (their connect runs beside the next extend anyway;
-        // fused, 265M-path calls measured -0.9 % on the bundled-like 4K scene, +2 % and +1 % on the two large trees), and so does
-        // per-stage timing.
-        const bool fuse = L.shared && c->cfg.stage_timing != 1;
+        // +0.6 %, the 8-spp soup frame +2 %), and so does every call over the quantised records (132M- and 265M-path calls on the
+        // two large trees: +2 % and +1 % against connect beside the next extend on a stream of its own; the same on the bundled-like
+        // 4K scene: -0.9 %, so lone calls over the exact records keep the stages apart).  With any stage timing on, every stage has
+        // launches of its own, so that the events around a launch bracket one kind of ray.
+        const bool fuse = c->cfg.stage_timing == 0 && (L.shared || walkMode(c) == PT_WALK_QUANT);
         bool connectDeferred = false;
         // a way out of this loop with a connect still running on its stream (a failed call below) waits for it: everything else
         // in the library orders itself after the context's main stream only
