@@ -744,9 +744,18 @@ static int traverseGrid(const pt_ctx* c, const LaneRef& L, int grid) {
 static void launchExtend(pt_ctx* c, const LaneRef& L, bool stats, int cur, uint32_t refillMin) {
     PT_LAUNCH_WALK(k_extend, stats, walkMode(c), dim3(traverseGrid(c, L, c->grid_extend)), dim3(PT_BLOCK), L.stream, c->sc, *L.q, L.d_ctl, cur, refillMin);
 }
-// extend of the queue `cur` and, in the same grid, connect of the shadow rays the bounce before left (k_connect_extend)
+// extend of the queue `cur` and, in the same grid, connect of the shadow rays the bounce before left (k_connect_extend; the walk over
+// instances keeps the stages apart and has no such kernel)
 static void launchConnectExtend(pt_ctx* c, const LaneRef& L, bool stats, int cur, uint32_t refillMin) {
-    PT_LAUNCH_WALK(k_connect_extend, stats, walkMode(c), dim3(traverseGrid(c, L, c->grid_extend)), dim3(PT_BLOCK), L.stream, c->sc, *L.q, L.d_ctl, cur, refillMin, bounceRefill(c));
+    const dim3 grid(traverseGrid(c, L, c->grid_extend)), block(PT_BLOCK);
+    const uint32_t refillShadow = bounceRefill(c);
+    if (walkMode(c) == PT_WALK_QUANT) {
+        if (stats) hipLaunchKernelGGL((k_connect_extend<true, PT_WALK_QUANT>), grid, block, 0, L.stream, c->sc, *L.q, L.d_ctl, cur, refillMin, refillShadow);
+        else hipLaunchKernelGGL((k_connect_extend<false, PT_WALK_QUANT>), grid, block, 0, L.stream, c->sc, *L.q, L.d_ctl, cur, refillMin, refillShadow);
+    } else {
+        if (stats) hipLaunchKernelGGL((k_connect_extend<true, PT_WALK_EXACT>), grid, block, 0, L.stream, c->sc, *L.q, L.d_ctl, cur, refillMin, refillShadow);
+        else hipLaunchKernelGGL((k_connect_extend<false, PT_WALK_EXACT>), grid, block, 0, L.stream, c->sc, *L.q, L.d_ctl, cur, refillMin, refillShadow);
+    }
 }
 static void launchConnect(pt_ctx* c, const LaneRef& L, bool stats, int cur, hipStream_t on) {
     PT_LAUNCH_WALK(k_connect, stats, walkMode(c), dim3(traverseGrid(c, L, c->grid_connect)), dim3(PT_BLOCK), on, c->sc, *L.q, L.d_ctl, cur, bounceRefill(c));
@@ -855,7 +864,7 @@ static int renderBatches(pt_ctx* c, const LaneRef* lanes, uint32_t n_lanes, uint
         // two large trees: +2 % and +1 % against connect beside the next extend on a stream of its own; the same on the bundled-like
         // 4K scene: -0.9 %, so lone calls over the exact records keep the stages apart).  With any stage timing on, every stage has
         // launches of its own, so that the events around a launch bracket one kind of ray.
-        const bool fuse = c->cfg.stage_timing == 0 && (L.shared || walkMode(c) == PT_WALK_QUANT);
+        const bool fuse = c->cfg.stage_timing == 0 && walkMode(c) != PT_WALK_INST && (L.shared || walkMode(c) == PT_WALK_QUANT);
         bool connectDeferred = false;
         // a way out of this loop with a connect still running on its stream (a failed call below) waits for it: everything else
         // in the library orders itself after the context's main stream only
