@@ -408,7 +408,9 @@ __device__ __forceinline__ void blockAppend2(bool a, bool b, uint32_t* counterA,
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 6
 #endif
+#ifndef PT_SHADE_BLOCK_SMALL
 #define PT_SHADE_BLOCK_SMALL 256
+#endif
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK, PT_SHADE_WAVES) k_shade(DevScene sc, RenderParams rp, Queues q, Ctl* ctl, int cur) {
     __shared__ uint32_t s_append[2][2 * (BLOCK / PT_WAVE) + 2];
