@@ -961,6 +961,31 @@ def test_full_size_frame_properties(pa, ob, bundled):
     assert np.array_equal(bits(imgs[1]), bits(imgs[0])) and np.array_equal(bits(imgs[2]), bits(imgs[0]))
 
 
+def test_full_size_frames_in_flight(pa, bundled):
+    """Three headline frames (1920x1080, 16 spp, 4 bounces, NEE) queued back to back, so that two are in flight and the calls take
+    the kernels of frames that share the GPU (four traversal blocks per CU, 256-thread shade blocks, connect inside the next extend
+    launch): the accumulated image and the ray counts are those of the same three calls with one set of queues, bit for bit."""
+    w, h = 1920, 1080
+    got = []
+    for pipe in (1, 0):
+        wf = make_wf(pa, bundled, nee=True, rng_mode=1)
+        wf.set_option(11, pipe)
+        wf.allocate(w, h)
+        fs = bundled_view(bundled, w, h, frames=1)
+        fs["samples"] = 0
+        for _ in range(3):
+            wf.invoke(fs, spp=16, max_bounces=4, wait=False)
+            fs["frames"] += 16
+            fs["samples"] += 16
+        img = wf.read_image()
+        st = wf.stats()
+        assert st["stack_overflows"] == 0
+        got.append((img, (st["paths"], st["extend_rays"], st["shadow_rays"])))
+        wf.close()
+    assert got[0][1][0] == w * h * 48 and got[0][1] == got[1][1]
+    assert np.array_equal(bits(got[0][0]), bits(got[1][0]))
+
+
 def test_million_triangle_soup_against_the_oracle(pa, ob):
     """The 1M-triangle configuration's scene at full size: GPU build == oracle build, and incoherent closest / any hits
     == the oracle's literal and canonical walks on a sample of rays."""
