@@ -945,6 +945,16 @@ static int impl_render(pt_ctx* c, const void* frame_state112, int32_t spp, int32
     // own set (halving them to have two in flight measured +1 % on a 265M-path call of 4 bounces and -4 % on one of 8 bounces).
     // With per-stage timing the stages of a call have the GPU to themselves, on the context's stream.
     uint32_t batch = chooseBatch(c, (uint32_t)spp);
+    // Over the exact records (traversal bound by instruction issue, shade by memory) a larger call is worth more as several batches
+    // of up to 64M paths that share the GPU two at a time than as one batch with the GPU to itself: 3840x2160 x 32 spp as four batches
+    // of 8 samples 59.1 -> 57.6 ms (as two of 16: 58.6, as eight of 4: 58.7).  Over the quantised records it is not (the 1M soup's
+    // 64 spp as eight batches of 8: 127 -> 138 ms; the 20M-triangle scene's 32 spp as four: 63 -> 68 ms): those keep the one batch.
+    if (c->cfg.samples_per_batch == 0 && c->pipeline_calls != 0 && c->cfg.stage_timing != 1 && walkMode(c) == PT_WALK_EXACT &&
+        (uint64_t)c->slots * batch > PT_PIPELINE_MAX_PATHS && c->slots != 0 && c->slots <= PT_PIPELINE_MAX_PATHS) {
+        const uint32_t most = (uint32_t)(PT_PIPELINE_MAX_PATHS / c->slots);
+        const uint32_t batches = ((uint32_t)spp + most - 1u) / most;
+        batch = ((uint32_t)spp + batches - 1u) / batches;
+    }
     const bool eligible = c->pipeline_calls != 0 && c->cfg.stage_timing != 1 && (uint64_t)c->slots * batch <= PT_PIPELINE_MAX_PATHS;
     LaneRef lanes[2] = {inlineLane(c), inlineLane(c)};
     uint32_t n_lanes = 1;
